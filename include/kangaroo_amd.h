@@ -1,0 +1,131 @@
+/*
+ * kangaroo_amd.h — C ABI of the MI355X (gfx950) kangaroo jump engine.
+ *
+ * This is the drop-in boundary: one entry point per member of the reference's
+ * `class GPUEngine` (math/gpu/engine.h:13-54 under /root/reference).  Plain C types only:
+ * every 256-bit value is four little-endian uint64_t limbs (the reference's
+ * Int::bits64[0..3]); kangaroos are indexed in the reference's host order
+ *     idx = block * (128 * threadsPerGroup) + g * threadsPerGroup + t,   type = idx % 2
+ * (math/gpu/engine.cu:281-326, math/gpu/compute.h:58).  How the engine lays the herd out in
+ * HBM is private.  kangaroo_amd/csrc/GPUEngine.cpp implements the C++ class on top of these
+ * calls; INTEGRATION.md shows how the reference links against it.
+ *
+ * All functions return KG_OK (0) or a negative KG_ERR_* code; kg_last_error() gives the
+ * message for the calling thread.  An engine is bound to one device and must be driven from
+ * one host thread at a time (one engine per GPU thread, as core/kangaroo.cpp:397-508 does).
+ */
+#ifndef KANGAROO_AMD_H
+#define KANGAROO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KG_OK 0
+#define KG_ERR_ARG (-1)      /* bad argument */
+#define KG_ERR_HIP (-2)      /* HIP runtime error (message has the HIP string) */
+#define KG_ERR_STATE (-3)    /* call out of order (e.g. collect without kick) */
+#define KG_ERR_LOST (-4)     /* more DPs than the output buffer holds; *lost tells how many */
+#define KG_ERR_NODEVICE (-5) /* no usable GPU */
+
+#define KG_GROUP_SIZE 128 /* GPU_GRP_SIZE, constants.h:15 */
+#define KG_NB_JUMP 64     /* NB_JUMP, constants.h:12 */
+#define KG_NB_RUN 256     /* NB_RUN, constants.h:21: default steps per launch */
+
+typedef struct kg_engine kg_engine;
+
+/* One distinguished point.  Replaces the 76-byte device item of math/gpu/kernel.h:154-173 and
+ * the host ITEM of math/cpu/int.h:339-343 (x, d, kIdx). d already has the wild offset removed
+ * (math/gpu/engine.cu:534). */
+typedef struct {
+  uint64_t x[4];
+  uint64_t d[4];
+  uint64_t kIdx;
+} kg_item;
+
+/* Number of usable devices.  Replaces the cudaGetDeviceCount checks of engine.cu:74-86. */
+int kg_device_count(int *count);
+
+/* Default launch geometry when *x <= 0 or *y <= 0.  Replaces GPUEngine::GetGridSize
+ * (math/gpu/engine.cu:191-219); the defaults are CU-count based instead of SM/core tables.
+ * Safe to call from any thread before an engine exists (core/kangaroo.cpp:712). */
+int kg_default_grid(int gpu_id, int *x, int *y);
+
+/* Replaces GPUEngine::GPUEngine (math/gpu/engine.cu:67-170): binds device gpu_id in the calling
+ * thread and allocates for 128 * groups * per_group kangaroos.  max_found is the caller's DP
+ * capacity hint (core/kangaroo.cpp:408 passes 131072); the engine never allocates less. */
+int kg_create(int gpu_id, int groups, int per_group, uint32_t max_found, kg_engine **out);
+/* Replaces GPUEngine::~GPUEngine (math/gpu/engine.cu:172-181). */
+int kg_destroy(kg_engine *e);
+
+/* "GPU #%d %s (%dx%d cores) Grid(%dx%d)" — GPUEngine::deviceName (math/gpu/engine.cu:101-107). */
+int kg_device_name(const kg_engine *e, char *buf, size_t buflen);
+/* Replaces GPUEngine::GetMemory (engine.cu:183-185), without the int overflow. */
+int kg_memory_bytes(const kg_engine *e, uint64_t *bytes);
+/* Replaces GPUEngine::GetNbThread (engine.cu:277-279): groups * per_group. */
+int kg_nb_thread(const kg_engine *e);
+/* Replaces GPUEngine::GetGroupSize (engine.cu:187-189): always 128. */
+int kg_group_size(const kg_engine *e);
+/* 128 * groups * per_group */
+uint64_t kg_nb_kangaroo(const kg_engine *e);
+
+/* Replaces GPUEngine::SetWildOffset (engine.cu:63-65): offset added (mod n) to the distance of
+ * odd-index kangaroos on upload and removed on download / DP output. */
+int kg_set_wild_offset(kg_engine *e, const uint64_t offset[4]);
+
+/* Replaces GPUEngine::SetParams (engine.cu:442-472): DP mask on x.bits64[3] and the 64-entry
+ * jump table, each array 64 x 4 limbs. */
+int kg_set_params(kg_engine *e, uint64_t dp_mask, const uint64_t *jump_dist, const uint64_t *jump_px,
+                  const uint64_t *jump_py);
+
+/* Replaces GPUEngine::SetKangaroos (engine.cu:281-326): n = kg_nb_kangaroo(e) entries of 4 limbs
+ * each, host index order; x, y must be canonical affine coordinates. */
+int kg_set_kangaroos(kg_engine *e, const uint64_t *px, const uint64_t *py, const uint64_t *d, uint64_t n);
+/* Replaces GPUEngine::GetKangaroos (engine.cu:328-383).  Waits for the launch in flight. */
+int kg_get_kangaroos(kg_engine *e, uint64_t *px, uint64_t *py, uint64_t *d, uint64_t n);
+/* Replaces GPUEngine::SetKangaroo (engine.cu:385-425): overwrite one kangaroo.  Ordered on the
+ * engine's stream: takes effect after the launch in flight and before the next one. */
+int kg_set_kangaroo(kg_engine *e, uint64_t k_idx, const uint64_t px[4], const uint64_t py[4],
+                    const uint64_t d[4]);
+
+/* Steps per launch (default KG_NB_RUN).  No counterpart in the reference, where NB_RUN is a
+ * compile-time constant (constants.h:21); used by the throughput sweep of BASELINE config 4. */
+int kg_set_nb_run(kg_engine *e, uint32_t nb_run);
+
+/* Replaces GPUEngine::callKernel (engine.cu:427-440): clear the DP counter and start one launch
+ * of nb_run steps for every kangaroo, asynchronously. */
+int kg_kick(kg_engine *e);
+/* First half of GPUEngine::Launch (engine.cu:486-537): wait for the launch in flight and copy out
+ * its DPs.  *n receives the item count stored (<= cap).  If the launch produced more than the
+ * engine's buffer or cap can hold, returns KG_ERR_LOST with *lost = number dropped. */
+int kg_collect(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *n, uint32_t *lost);
+/* GPUEngine::Launch (engine.cu:486-539): collect the launch in flight, start the next one. The
+ * next launch is queued before the items are unpacked, so host work overlaps the GPU. */
+int kg_launch(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *n, uint32_t *lost);
+/* Replaces GPUEngine::callKernelAndWait (engine.cu:474-484): kick + wait, DPs stay queued for the
+ * next kg_collect. */
+int kg_kick_and_wait(kg_engine *e);
+
+/* Duration in milliseconds of the last completed launch's kernel, measured with HIP events on the
+ * engine's stream (bench.py's roofline figure).  No counterpart in the reference. */
+int kg_last_kernel_ms(const kg_engine *e, float *ms);
+/* Kernel variant in use: kangaroos per lane, distance-delta words, LDS bytes per workgroup,
+ * workgroups launched.  No counterpart in the reference. */
+int kg_kernel_info(const kg_engine *e, int *k_per_lane, int *delta_words, int *lds_bytes, int *grid);
+
+/* Replaces GPUEngine::AllocatePinnedMemory / FreePinnedMemory (engine.cu:221-233). */
+void *kg_alloc_pinned(size_t size);
+void kg_free_pinned(void *p);
+/* Replaces GPUEngine::PrintCudaInfo (engine.cu:235-275): one line per device on stdout. */
+int kg_print_device_info(void);
+
+const char *kg_last_error(void);
+const char *kg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,588 @@
+// engine_capi.hip — C-ABI implementation (include/kangaroo_amd.h) over the HIP walk kernel.
+//
+// Host half of the drop-in for the reference's GPUEngine (math/gpu/engine.cu).  Differences that
+// are deliberate and MI355X-first:
+//   * one private stream per engine, two DP buffers: launch i+1 is queued before the DPs of
+//     launch i are unpacked (the reference re-launches only after unpacking, engine.cu:515-538);
+//   * DP items land directly in host-visible pinned memory; only the 4-byte counter is copied;
+//   * the herd is stored as 12 lane-contiguous uint64 planes indexed by host kangaroo index
+//     (no per-block pinned repacking loop as in engine.cu:289-320);
+//   * SetKangaroo is a 1-thread kernel on the same stream instead of twelve blocking 8-byte
+//     copies (engine.cu:385-425), so it is ordered between launches without stalling the host.
+// There is NO CPU fallback: every entry point that computes needs a gfx950 device.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/kangaroo_amd.h"
+#include "walk_kernel.h"
+
+using namespace kg;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess)                                                                             \
+      return fail(KG_ERR_HIP, std::string("GPUEngine: ") + #expr + ": " + hipGetErrorString(_e));     \
+  } while (0)
+
+// group order n (math/secp256k1.cpp:17), little-endian limbs
+static const u64 ORDER_N[4] = {0xBFD25E8CD0364141ULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFEULL,
+                               0xFFFFFFFFFFFFFFFFULL};
+
+// r = a + b mod n for a, b < 2^256 (Int::ModAddK1order, math/cpu/intmod.cpp:837-842)
+static void order_add(u64 r[4], const u64 a[4], const u64 b[4]) {
+  unsigned __int128 c = 0;
+  u64 t[4], s[4];
+  for (int i = 0; i < 4; ++i) {
+    c += (unsigned __int128)a[i] + b[i];
+    t[i] = (u64)c;
+    c >>= 64;
+  }
+  u64 carry = (u64)c, br = 0;
+  for (int i = 0; i < 4; ++i) {
+    unsigned __int128 d = (unsigned __int128)t[i] - ORDER_N[i] - br;
+    s[i] = (u64)d;
+    br = (u64)(d >> 64) & 1;
+  }
+  const bool negative = (carry == 0) && br;
+  memcpy(r, negative ? t : s, 32);
+}
+// r = a - b mod n (Int::ModSubK1order, math/cpu/intmod.cpp:844-848)
+static void order_sub(u64 r[4], const u64 a[4], const u64 b[4]) {
+  u64 t[4], br = 0;
+  for (int i = 0; i < 4; ++i) {
+    unsigned __int128 d = (unsigned __int128)a[i] - b[i] - br;
+    t[i] = (u64)d;
+    br = (u64)(d >> 64) & 1;
+  }
+  if (br) {
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 4; ++i) {
+      c += (unsigned __int128)t[i] + ORDER_N[i];
+      t[i] = (u64)c;
+      c >>= 64;
+    }
+  }
+  memcpy(r, t, 32);
+}
+
+struct kg_engine {
+  int gpu = 0, groups = 0, per_group = 0;
+  u64 n = 0, cap = 0;
+  u32 threads = 0, grid = 0;
+  int K = 0, DW = 0;
+  u32 nb_run = KG_NB_RUN;
+  u32 max_found = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start[2] = {nullptr, nullptr}, ev_stop[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+  u64 *X = nullptr, *Y = nullptr, *D = nullptr;
+  JumpTableDev *jt = nullptr;
+  DpItemDev *out_host[2] = {nullptr, nullptr};
+  DpItemDev *out_dev[2] = {nullptr, nullptr};
+  u32 *count_dev = nullptr;   // [2]
+  u32 *count_host = nullptr;  // pinned [2]
+  u64 *stage = nullptr;       // pinned staging for herd upload/download
+  size_t stage_elems = 0;
+  u64 wild[4] = {0, 0, 0, 0};
+  u64 dp_mask = 0;
+  int max_jd_bits = 0;
+  bool params_set = false, herd_set = false;
+  int inflight = -1, next_buf = 0;
+  int pending = -1;  // completed by kick_and_wait, not yet collected
+  float last_ms = 0.f;
+  int cus = 0;
+  char name[256] = {0};
+};
+
+// ---- kernel dispatch ------------------------------------------------------------------------
+typedef void (*walk_fn)(WalkArgs);
+struct Variant {
+  int K, DW;
+  walk_fn fn;
+};
+#define KG_VARIANT(K, DW) {K, DW, kg_walk_kernel<K, DW>}
+static const Variant g_variants[] = {
+    KG_VARIANT(1, 3),  KG_VARIANT(1, 8),  KG_VARIANT(4, 3),  KG_VARIANT(4, 8),  KG_VARIANT(8, 3),
+    KG_VARIANT(8, 8),  KG_VARIANT(12, 3), KG_VARIANT(12, 8), KG_VARIANT(16, 3), KG_VARIANT(16, 8),
+};
+
+static const Variant *find_variant(int K, int DW) {
+  for (const Variant &v : g_variants)
+    if (v.K == K && v.DW == DW) return &v;
+  return nullptr;
+}
+
+static int default_k() {
+  const char *s = getenv("KG_K");  // experiment knob; the default is the measured best
+  if (s && *s) {
+    int k = atoi(s);
+    if (find_variant(k, 3)) return k;
+  }
+  return 8;
+}
+
+static int bit_length256(const u64 v[4]) {
+  for (int i = 3; i >= 0; --i)
+    if (v[i]) return 64 * i + 64 - __builtin_clzll(v[i]);
+  return 0;
+}
+
+__global__ void kg_poke_kernel(u64 *X, u64 *Y, u64 *D, u64 cap, u64 p, u64 x0, u64 x1, u64 x2, u64 x3, u64 y0,
+                               u64 y1, u64 y2, u64 y3, u64 d0, u64 d1, u64 d2, u64 d3) {
+  X[0 * cap + p] = x0; X[1 * cap + p] = x1; X[2 * cap + p] = x2; X[3 * cap + p] = x3;
+  Y[0 * cap + p] = y0; Y[1 * cap + p] = y1; Y[2 * cap + p] = y2; Y[3 * cap + p] = y3;
+  D[0 * cap + p] = d0; D[1 * cap + p] = d1; D[2 * cap + p] = d2; D[3 * cap + p] = d3;
+}
+
+// ---- device queries ------------------------------------------------------------------------------
+extern "C" int kg_device_count(int *count) {
+  if (!count) return fail(KG_ERR_ARG, "kg_device_count: null argument");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(KG_ERR_HIP, std::string("GPUEngine: hipGetDeviceCount ") + hipGetErrorString(e));
+  }
+  *count = c;
+  return KG_OK;
+}
+
+extern "C" int kg_default_grid(int gpu_id, int *x, int *y) {
+  if (!x || !y) return fail(KG_ERR_ARG, "kg_default_grid: null argument");
+  if (*x > 0 && *y > 0) return KG_OK;
+  int c = 0;
+  if (kg_device_count(&c) != KG_OK) return KG_ERR_HIP;
+  if (c == 0) return fail(KG_ERR_NODEVICE, "GPUEngine: There are no available device(s) that support HIP");
+  if (gpu_id < 0 || gpu_id >= c) return fail(KG_ERR_ARG, "GPUEngine::GetGridSize() Invalid gpuId");
+  int cus = 0;
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_id));
+  // 2 groups per CU x 128 threads x 128 kangaroos: 8.4 M kangaroos on 256 CUs (0.8 GB of state)
+  if (*x <= 0) *x = 2 * cus;
+  if (*y <= 0) *y = 128;
+  return KG_OK;
+}
+
+extern "C" int kg_print_device_info(void) {
+  int c = 0;
+  if (kg_device_count(&c) != KG_OK) return KG_ERR_HIP;
+  for (int i = 0; i < c; ++i) {
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, i));
+    printf("GPU #%d %s (%d CUs) (%s) (%.1f MB)\n", i, p.name, p.multiProcessorCount, p.gcnArchName,
+           (double)p.totalGlobalMem / 1048576.0);
+  }
+  return KG_OK;
+}
+
+extern "C" void *kg_alloc_pinned(size_t size) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, size, hipHostMallocPortable) != hipSuccess) {
+    g_err = "GPUEngine: AllocatePinnedMemory failed";
+    return nullptr;
+  }
+  return p;
+}
+extern "C" void kg_free_pinned(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
+extern "C" const char *kg_last_error(void) { return g_err.c_str(); }
+extern "C" const char *kg_version(void) { return "kangaroo_amd 0.1 (gfx950)"; }
+
+// ---- lifetime ---------------------------------------------------------------------------------------
+static int bind(const kg_engine *e) {
+  HIPCHK(hipSetDevice(e->gpu));
+  return KG_OK;
+}
+
+extern "C" int kg_destroy(kg_engine *e) {
+  if (!e) return KG_OK;
+  (void)hipSetDevice(e->gpu);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (int b = 0; b < 2; ++b) {
+    if (e->ev_start[b]) (void)hipEventDestroy(e->ev_start[b]);
+    if (e->ev_stop[b]) (void)hipEventDestroy(e->ev_stop[b]);
+    if (e->ev_done[b]) (void)hipEventDestroy(e->ev_done[b]);
+    if (e->out_host[b]) (void)hipHostFree(e->out_host[b]);
+  }
+  if (e->X) (void)hipFree(e->X);
+  if (e->Y) (void)hipFree(e->Y);
+  if (e->D) (void)hipFree(e->D);
+  if (e->jt) (void)hipFree(e->jt);
+  if (e->count_dev) (void)hipFree(e->count_dev);
+  if (e->count_host) (void)hipHostFree(e->count_host);
+  if (e->stage) (void)hipHostFree(e->stage);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+  return KG_OK;
+}
+
+extern "C" int kg_create(int gpu_id, int groups, int per_group, uint32_t max_found, kg_engine **out) {
+  if (!out) return fail(KG_ERR_ARG, "kg_create: null out pointer");
+  *out = nullptr;
+  if (groups <= 0 || per_group <= 0) return fail(KG_ERR_ARG, "kg_create: grid must be positive");
+  int c = 0;
+  if (kg_device_count(&c) != KG_OK) return KG_ERR_HIP;
+  if (c == 0) return fail(KG_ERR_NODEVICE, "GPUEngine: There are no available device(s) that support HIP");
+  if (gpu_id < 0 || gpu_id >= c) return fail(KG_ERR_ARG, "GPUEngine: invalid gpuId");
+  hipError_t he = hipSetDevice(gpu_id);
+  if (he != hipSuccess) return fail(KG_ERR_HIP, std::string("GPUEngine: ") + hipGetErrorString(he));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, gpu_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(KG_ERR_NODEVICE, std::string("GPUEngine: device is ") + prop.gcnArchName +
+                                     ", this engine is built for gfx950 only");
+
+  kg_engine *e = new kg_engine();
+  e->gpu = gpu_id;
+  e->groups = groups;
+  e->per_group = per_group;
+  e->cus = prop.multiProcessorCount;
+  e->n = (u64)KG_GROUP_SIZE * (u64)groups * (u64)per_group;
+  e->K = default_k();
+  e->DW = 3;
+  const u64 per_lane = (e->n + e->K - 1) / e->K;
+  const u64 blocks = (per_lane + WALK_BLOCK - 1) / WALK_BLOCK;
+  if (blocks > 0x7FFFFFFFull) {
+    delete e;
+    return fail(KG_ERR_ARG, "kg_create: herd too large");
+  }
+  e->grid = (u32)blocks;
+  e->threads = e->grid * WALK_BLOCK;
+  e->cap = (u64)e->threads * e->K;
+  // the caller's maxFound is a hint (core/kangaroo.cpp:408); never smaller than it, and large
+  // enough for one DP per kangaroo per launch up to 4M items so that low-DP runs do not drop items
+  e->max_found = std::max<u32>(max_found, (u32)std::min<u64>(e->n, 1u << 22));
+  snprintf(e->name, sizeof e->name, "GPU #%d %s (%dx%d cores) Grid(%dx%d)", gpu_id, prop.name,
+           prop.multiProcessorCount, 64 * 4, groups, per_group);
+
+#define CRT(expr)                                                                       \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      std::string m = std::string("GPUEngine: ") + #expr + ": " + hipGetErrorString(_e); \
+      kg_destroy(e);                                                                    \
+      return fail(KG_ERR_HIP, m);                                                       \
+    }                                                                                   \
+  } while (0)
+  CRT(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  for (int b = 0; b < 2; ++b) {
+    CRT(hipEventCreate(&e->ev_start[b]));
+    CRT(hipEventCreate(&e->ev_stop[b]));
+    CRT(hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
+  }
+  const size_t plane_bytes = (size_t)e->cap * 4 * sizeof(u64);
+  CRT(hipMalloc((void **)&e->X, plane_bytes));
+  CRT(hipMalloc((void **)&e->Y, plane_bytes));
+  CRT(hipMalloc((void **)&e->D, plane_bytes));
+  CRT(hipMalloc((void **)&e->jt, sizeof(JumpTableDev)));
+  CRT(hipMalloc((void **)&e->count_dev, 2 * sizeof(u32)));
+  CRT(hipHostMalloc((void **)&e->count_host, 2 * sizeof(u32), hipHostMallocDefault));
+  for (int b = 0; b < 2; ++b) {
+    CRT(hipHostMalloc((void **)&e->out_host[b], (size_t)e->max_found * sizeof(DpItemDev),
+                      hipHostMallocMapped));
+    CRT(hipHostGetDevicePointer((void **)&e->out_dev[b], e->out_host[b], 0));
+  }
+  e->stage_elems = (size_t)std::min<u64>(e->cap, 1u << 20);
+  CRT(hipHostMalloc((void **)&e->stage, e->stage_elems * 12 * sizeof(u64), hipHostMallocDefault));
+  CRT(hipMemsetAsync(e->count_dev, 0, 2 * sizeof(u32), e->stream));
+  CRT(hipStreamSynchronize(e->stream));
+#undef CRT
+  *out = e;
+  return KG_OK;
+}
+
+// ---- accessors ----------------------------------------------------------------------------------------
+extern "C" int kg_device_name(const kg_engine *e, char *buf, size_t buflen) {
+  if (!e || !buf || !buflen) return fail(KG_ERR_ARG, "kg_device_name: bad argument");
+  snprintf(buf, buflen, "%s", e->name);
+  return KG_OK;
+}
+extern "C" int kg_memory_bytes(const kg_engine *e, uint64_t *bytes) {
+  if (!e || !bytes) return fail(KG_ERR_ARG, "kg_memory_bytes: bad argument");
+  *bytes = (u64)e->cap * 12 * sizeof(u64) + 2ull * e->max_found * sizeof(DpItemDev) + sizeof(JumpTableDev);
+  return KG_OK;
+}
+extern "C" int kg_nb_thread(const kg_engine *e) { return e ? e->groups * e->per_group : 0; }
+extern "C" int kg_group_size(const kg_engine *) { return KG_GROUP_SIZE; }
+extern "C" uint64_t kg_nb_kangaroo(const kg_engine *e) { return e ? e->n : 0; }
+
+extern "C" int kg_set_wild_offset(kg_engine *e, const uint64_t offset[4]) {
+  if (!e || !offset) return fail(KG_ERR_ARG, "kg_set_wild_offset: bad argument");
+  memcpy(e->wild, offset, 32);
+  return KG_OK;
+}
+
+extern "C" int kg_set_nb_run(kg_engine *e, uint32_t nb_run) {
+  if (!e || nb_run == 0) return fail(KG_ERR_ARG, "kg_set_nb_run: bad argument");
+  e->nb_run = nb_run;
+  return KG_OK;
+}
+
+static int pick_delta_words(const kg_engine *e) {
+  // delta accumulates nb_run jump distances: needs max_jd_bits + ceil(log2(nb_run)) bits
+  int lg = 0;
+  while ((1ull << lg) < e->nb_run) ++lg;
+  const int need = e->max_jd_bits + lg;
+  return need <= 96 ? 3 : 8;
+}
+
+extern "C" int kg_set_params(kg_engine *e, uint64_t dp_mask, const uint64_t *jd, const uint64_t *jpx,
+                             const uint64_t *jpy) {
+  if (!e || !jd || !jpx || !jpy) return fail(KG_ERR_ARG, "kg_set_params: bad argument");
+  if (bind(e) != KG_OK) return KG_ERR_HIP;
+  JumpTableDev h;
+  e->max_jd_bits = 0;
+  for (int i = 0; i < KG_NB_JUMP; ++i) {
+    u32 w[8];
+    fe f;
+    for (int k = 0; k < 4; ++k) {
+      w[2 * k] = (u32)jpx[4 * i + k];
+      w[2 * k + 1] = (u32)(jpx[4 * i + k] >> 32);
+    }
+    fe_from_words(f, w);
+    fe_canon(f);
+    for (int k = 0; k < 9; ++k) h.pxy[i][k] = f.l[k];
+    for (int k = 0; k < 4; ++k) {
+      w[2 * k] = (u32)jpy[4 * i + k];
+      w[2 * k + 1] = (u32)(jpy[4 * i + k] >> 32);
+    }
+    fe_from_words(f, w);
+    fe_canon(f);
+    for (int k = 0; k < 9; ++k) h.pxy[i][9 + k] = f.l[k];
+    for (int k = 0; k < 4; ++k) {
+      h.dist[i][2 * k] = (u32)jd[4 * i + k];
+      h.dist[i][2 * k + 1] = (u32)(jd[4 * i + k] >> 32);
+    }
+    e->max_jd_bits = std::max(e->max_jd_bits, bit_length256(jd + 4 * i));
+  }
+  e->dp_mask = dp_mask;
+  // ordered on the engine's stream behind any launch in flight
+  HIPCHK(hipMemcpyAsync(e->jt, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->params_set = true;
+  return KG_OK;
+}
+
+// ---- herd upload / download --------------------------------------------------------------------------
+static int wait_idle(kg_engine *e) {
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return KG_OK;
+}
+
+extern "C" int kg_set_kangaroos(kg_engine *e, const uint64_t *px, const uint64_t *py, const uint64_t *d, uint64_t n) {
+  if (!e || !px || !py || !d) return fail(KG_ERR_ARG, "kg_set_kangaroos: bad argument");
+  if (n != e->n) return fail(KG_ERR_ARG, "kg_set_kangaroos: n must equal kg_nb_kangaroo()");
+  if (bind(e) != KG_OK || wait_idle(e) != KG_OK) return KG_ERR_HIP;
+  const size_t chunk = e->stage_elems;
+  u64 *sx = e->stage, *sy = e->stage + 4 * chunk, *sd = e->stage + 8 * chunk;
+  for (u64 p0 = 0; p0 < e->cap; p0 += chunk) {
+    const u64 cnt = std::min<u64>(chunk, e->cap - p0);
+    for (u64 i = 0; i < cnt; ++i) {
+      const u64 p = p0 + i;
+      const u64 src = p < n ? p : 0;  // padding lanes replay kangaroo 0 (never reported: p >= n)
+      u64 dd[4];
+      if (src & 1) order_add(dd, d + 4 * src, e->wild);  // engine.cu:305-308
+      else memcpy(dd, d + 4 * src, 32);
+      for (int w = 0; w < 4; ++w) {
+        sx[(size_t)w * chunk + i] = px[4 * src + w];
+        sy[(size_t)w * chunk + i] = py[4 * src + w];
+        sd[(size_t)w * chunk + i] = dd[w];
+      }
+    }
+    for (int w = 0; w < 4; ++w) {
+      HIPCHK(hipMemcpyAsync(e->X + (u64)w * e->cap + p0, sx + (size_t)w * chunk, cnt * 8, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(e->Y + (u64)w * e->cap + p0, sy + (size_t)w * chunk, cnt * 8, hipMemcpyHostToDevice, e->stream));
+      HIPCHK(hipMemcpyAsync(e->D + (u64)w * e->cap + p0, sd + (size_t)w * chunk, cnt * 8, hipMemcpyHostToDevice, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+  }
+  e->herd_set = true;
+  return KG_OK;
+}
+
+extern "C" int kg_get_kangaroos(kg_engine *e, uint64_t *px, uint64_t *py, uint64_t *d, uint64_t n) {
+  if (!e || !px || !py || !d) return fail(KG_ERR_ARG, "kg_get_kangaroos: bad argument");
+  if (n != e->n) return fail(KG_ERR_ARG, "kg_get_kangaroos: n must equal kg_nb_kangaroo()");
+  if (bind(e) != KG_OK || wait_idle(e) != KG_OK) return KG_ERR_HIP;
+  const size_t chunk = e->stage_elems;
+  u64 *sx = e->stage, *sy = e->stage + 4 * chunk, *sd = e->stage + 8 * chunk;
+  for (u64 p0 = 0; p0 < n; p0 += chunk) {
+    const u64 cnt = std::min<u64>(chunk, n - p0);
+    for (int w = 0; w < 4; ++w) {
+      HIPCHK(hipMemcpyAsync(sx + (size_t)w * chunk, e->X + (u64)w * e->cap + p0, cnt * 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(sy + (size_t)w * chunk, e->Y + (u64)w * e->cap + p0, cnt * 8, hipMemcpyDeviceToHost, e->stream));
+      HIPCHK(hipMemcpyAsync(sd + (size_t)w * chunk, e->D + (u64)w * e->cap + p0, cnt * 8, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (u64 i = 0; i < cnt; ++i) {
+      const u64 p = p0 + i;
+      u64 dd[4];
+      for (int w = 0; w < 4; ++w) {
+        px[4 * p + w] = sx[(size_t)w * chunk + i];
+        py[4 * p + w] = sy[(size_t)w * chunk + i];
+        dd[w] = sd[(size_t)w * chunk + i];
+      }
+      if (p & 1) order_sub(dd, dd, e->wild);  // engine.cu:371
+      memcpy(d + 4 * p, dd, 32);
+    }
+  }
+  return KG_OK;
+}
+
+extern "C" int kg_set_kangaroo(kg_engine *e, uint64_t k_idx, const uint64_t px[4], const uint64_t py[4],
+                               const uint64_t d[4]) {
+  if (!e || !px || !py || !d) return fail(KG_ERR_ARG, "kg_set_kangaroo: bad argument");
+  if (k_idx >= e->n) return fail(KG_ERR_ARG, "kg_set_kangaroo: kIdx out of range");
+  if (bind(e) != KG_OK) return KG_ERR_HIP;
+  u64 dd[4];
+  if (k_idx & 1) order_add(dd, d, e->wild);  // engine.cu:414-416
+  else memcpy(dd, d, 32);
+  hipLaunchKernelGGL(kg_poke_kernel, dim3(1), dim3(1), 0, e->stream, e->X, e->Y, e->D, e->cap, (u64)k_idx, px[0],
+                     px[1], px[2], px[3], py[0], py[1], py[2], py[3], dd[0], dd[1], dd[2], dd[3]);
+  HIPCHK(hipGetLastError());
+  return KG_OK;
+}
+
+// ---- launch / collect ------------------------------------------------------------------------------------
+extern "C" int kg_kick(kg_engine *e) {
+  if (!e) return fail(KG_ERR_ARG, "kg_kick: null engine");
+  if (!e->params_set || !e->herd_set) return fail(KG_ERR_STATE, "GPUEngine: Kernel: SetParams/SetKangaroos not called");
+  if (e->inflight >= 0) return fail(KG_ERR_STATE, "GPUEngine: Kernel: a launch is already in flight");
+  if (e->pending >= 0) return fail(KG_ERR_STATE, "GPUEngine: Kernel: previous launch not collected");
+  if (bind(e) != KG_OK) return KG_ERR_HIP;
+  e->DW = pick_delta_words(e);
+  const Variant *v = find_variant(e->K, e->DW);
+  if (!v) return fail(KG_ERR_STATE, "GPUEngine: Kernel: no kernel variant for this configuration");
+  const int b = e->next_buf;
+  WalkArgs a;
+  a.X = e->X;
+  a.Y = e->Y;
+  a.D = e->D;
+  a.cap = e->cap;
+  a.n = e->n;
+  a.threads = e->threads;
+  a.nb_run = e->nb_run;
+  a.dp_mask_hi = (u32)(e->dp_mask >> 32);
+  a.dp_mask_lo = (u32)e->dp_mask;
+  a.jt = e->jt;
+  a.out = e->out_dev[b];
+  a.out_count = e->count_dev + b;
+  a.max_found = e->max_found;
+  const size_t lds = walk_lds_bytes(e->K, e->DW);
+  if (lds > 64 * 1024)  // above the default dynamic-LDS limit (gfx950 has 160 KiB per CU)
+    HIPCHK(hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(hipMemsetAsync(e->count_dev + b, 0, sizeof(u32), e->stream));
+  HIPCHK(hipEventRecord(e->ev_start[b], e->stream));
+  hipLaunchKernelGGL(v->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(e->ev_stop[b], e->stream));
+  HIPCHK(hipMemcpyAsync(e->count_host + b, e->count_dev + b, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipEventRecord(e->ev_done[b], e->stream));
+  e->inflight = b;
+  e->next_buf = b ^ 1;
+  return KG_OK;
+}
+
+static int wait_launch(kg_engine *e, int b) {
+  HIPCHK(hipEventSynchronize(e->ev_done[b]));
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, e->ev_start[b], e->ev_stop[b]) == hipSuccess) e->last_ms = ms;
+  return KG_OK;
+}
+
+static int unpack(kg_engine *e, int b, kg_item *items, uint32_t cap, uint32_t *n, uint32_t *lost) {
+  const u32 found = e->count_host[b];
+  const u32 stored = std::min(found, e->max_found);
+  const u32 take = std::min(stored, cap);
+  const DpItemDev *src = e->out_host[b];
+  for (u32 i = 0; i < take; ++i) {
+    kg_item &it = items[i];
+    for (int k = 0; k < 4; ++k) {
+      it.x[k] = (u64)src[i].x[2 * k] | ((u64)src[i].x[2 * k + 1] << 32);
+      it.d[k] = (u64)src[i].d[2 * k] | ((u64)src[i].d[2 * k + 1] << 32);
+    }
+    it.kIdx = src[i].kidx;
+    if (it.kIdx & 1) order_sub(it.d, it.d, e->wild);  // engine.cu:534
+  }
+  if (n) *n = take;
+  const u32 dropped = found - take;
+  if (lost) *lost = dropped;
+  if (dropped) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "Error: %u items lost\nHint: Search with less threads (-g) or increase dp (-d)", dropped);
+    return fail(KG_ERR_LOST, msg);
+  }
+  return KG_OK;
+}
+
+extern "C" int kg_collect(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *n, uint32_t *lost) {
+  if (!e || (!items && cap)) return fail(KG_ERR_ARG, "kg_collect: bad argument");
+  if (n) *n = 0;
+  if (lost) *lost = 0;
+  int b = e->pending;
+  if (b < 0) {
+    b = e->inflight;
+    if (b < 0) return fail(KG_ERR_STATE, "GPUEngine: Launch: no launch in flight");
+    if (bind(e) != KG_OK || wait_launch(e, b) != KG_OK) return KG_ERR_HIP;
+    e->inflight = -1;
+  }
+  e->pending = -1;
+  return unpack(e, b, items, cap, n, lost);
+}
+
+extern "C" int kg_launch(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *n, uint32_t *lost) {
+  if (!e || (!items && cap)) return fail(KG_ERR_ARG, "kg_launch: bad argument");
+  if (n) *n = 0;
+  if (lost) *lost = 0;
+  int b = e->pending;
+  if (b < 0) {
+    b = e->inflight;
+    if (b < 0) return fail(KG_ERR_STATE, "GPUEngine: Launch: no launch in flight");
+    if (bind(e) != KG_OK || wait_launch(e, b) != KG_OK) return KG_ERR_HIP;
+    e->inflight = -1;
+  }
+  e->pending = -1;
+  // queue the next launch first: the GPU walks while the host unpacks buffer b
+  const int rk = kg_kick(e);
+  const int ru = unpack(e, b, items, cap, n, lost);
+  return ru != KG_OK ? ru : rk;
+}
+
+extern "C" int kg_kick_and_wait(kg_engine *e) {
+  const int r = kg_kick(e);
+  if (r != KG_OK) return r;
+  const int b = e->inflight;
+  if (wait_launch(e, b) != KG_OK) return KG_ERR_HIP;
+  e->inflight = -1;
+  e->pending = b;
+  return KG_OK;
+}
+
+extern "C" int kg_last_kernel_ms(const kg_engine *e, float *ms) {
+  if (!e || !ms) return fail(KG_ERR_ARG, "kg_last_kernel_ms: bad argument");
+  *ms = e->last_ms;
+  return KG_OK;
+}
+
+extern "C" int kg_kernel_info(const kg_engine *e, int *k_per_lane, int *delta_words, int *lds_bytes, int *grid) {
+  if (!e) return fail(KG_ERR_ARG, "kg_kernel_info: null engine");
+  const int dw = e->params_set ? pick_delta_words(e) : e->DW;
+  if (k_per_lane) *k_per_lane = e->K;
+  if (delta_words) *delta_words = dw;
+  if (lds_bytes) *lds_bytes = (int)walk_lds_bytes(e->K, dw);
+  if (grid) *grid = (int)e->grid;
+  return KG_OK;
+}

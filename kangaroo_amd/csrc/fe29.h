@@ -1,0 +1,238 @@
+// fe29.h — secp256k1 field arithmetic for gfx950, 9 limbs of 29 bits in 32-bit VGPRs.
+//
+// Why not 4x64 / 8x32 saturated limbs: measured on MI355X (profiles/ubench_r01.txt) a carry
+// instruction (v_add_co/v_addc_co_u32) costs as much issue time as a v_mad_u64_u32 (4.3-5
+// cycles per wave64 against 2.5 for a plain 32-bit op) and every VCC producer->consumer pair
+// needs two wait states.  With 29-bit limbs the 81 partial products of a 256x256 multiply are
+// accumulated by v_mad_u64_u32 straight into 64-bit column sums that cannot overflow
+// (9 * 2^31 * 2^29 < 2^64), no carry flag is ever used, and subtraction is limb-wise.
+//
+// Values: v = sum l[i] * 2^(29 i).  Three states are used:
+//   canonical : v in [0,p), l[0..7] < 2^29, l[8] < 2^24
+//   weak      : l[0] < 2^29 + 2^18, l[1] < 2^29 + 2^11, l[2..7] < 2^29 (+1), l[8] <= 2^24;  v < 2^256 + 2^50
+//   wide      : l[i] < 2^32 (a limb-wise a + c*p - b that has not been carried);   v < 2^259
+// fe_mul takes (wide, weak) and returns weak; fe_sqr takes weak and returns weak.
+//
+// The reference computes the same residues with a lazy two-fold reduction
+// (math/cpu/intmod.cpp:545-593, math/gpu/kernel.h:659-749) whose 256-bit output is canonical
+// unless it lands in [p, 2^256) (density 2^-223); fe_canon() returns the canonical
+// representative, so results are bit-identical to the reference wherever the reference's
+// own value is canonical (see DESIGN.md "lazy reduction").
+//
+// The file is plain C++ so that tests can also compile it for the host (tests/fe_host.cpp);
+// the product only ever runs it inside the HIP kernels.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define KG_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define KG_HD static inline
+#endif
+
+namespace kg {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+constexpr u32 M29 = 0x1FFFFFFFu;
+constexpr u32 FE_R0 = 0x7A20u;  // 2^261 = 2^37 + 0x7A20 (mod p): low part
+constexpr u32 FE_R1 = 256u;     //   2^37 = 256 * 2^29
+
+struct fe {
+  u32 l[9];
+};
+
+// 2p and 4p with every limb lifted so that limb-wise (a + B - b) cannot go negative
+#define KG_B2_INIT {0x5ffff85eu, 0x5fffffedu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x5ffffffdu, 0x1fffffdu}
+#define KG_B4_INIT {0x9ffff0bcu, 0x9fffffdbu, 0x9ffffffbu, 0x9ffffffbu, 0x9ffffffbu, 0x9ffffffbu, 0x9ffffffbu, 0x9ffffffbu, 0x3fffffbu}
+
+KG_HD u32 fe_b2(int i) {
+  return i == 0 ? 0x5ffff85eu : i == 1 ? 0x5fffffedu : i == 8 ? 0x1fffffdu : 0x5ffffffdu;
+}
+KG_HD u32 fe_b4(int i) {
+  return i == 0 ? 0x9ffff0bcu : i == 1 ? 0x9fffffdbu : i == 8 ? 0x3fffffbu : 0x9ffffffbu;
+}
+
+// ---- conversion: eight 32-bit words (little endian) <-> nine 29-bit limbs ------------
+KG_HD void fe_from_words(fe &r, const u32 w[8]) {
+  r.l[0] = w[0] & M29;
+  r.l[1] = ((w[0] >> 29) | (w[1] << 3)) & M29;
+  r.l[2] = ((w[1] >> 26) | (w[2] << 6)) & M29;
+  r.l[3] = ((w[2] >> 23) | (w[3] << 9)) & M29;
+  r.l[4] = ((w[3] >> 20) | (w[4] << 12)) & M29;
+  r.l[5] = ((w[4] >> 17) | (w[5] << 15)) & M29;
+  r.l[6] = ((w[5] >> 14) | (w[6] << 18)) & M29;
+  r.l[7] = ((w[6] >> 11) | (w[7] << 21)) & M29;
+  r.l[8] = w[7] >> 8;
+}
+// input must be canonical (or at least fully carried with l[8] < 2^24)
+KG_HD void fe_to_words(u32 w[8], const fe &a) {
+  w[0] = a.l[0] | (a.l[1] << 29);
+  w[1] = (a.l[1] >> 3) | (a.l[2] << 26);
+  w[2] = (a.l[2] >> 6) | (a.l[3] << 23);
+  w[3] = (a.l[3] >> 9) | (a.l[4] << 20);
+  w[4] = (a.l[4] >> 12) | (a.l[5] << 17);
+  w[5] = (a.l[5] >> 15) | (a.l[6] << 14);
+  w[6] = (a.l[6] >> 18) | (a.l[7] << 11);
+  w[7] = (a.l[7] >> 21) | (a.l[8] << 8);
+}
+
+// ---- limb-wise subtraction, no carries: r = a - b (+2p), result is WIDE ----------------
+// a: limbs < 2^29 + 2^18 (weak);  b: limbs <= 2^30 - 3 and b.l[8] <= 2^25 - 3
+KG_HD void fe_sub_wide(fe &r, const fe &a, const fe &b) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + fe_b2(i) - b.l[i];
+}
+// r = a - b - c (+4p), WIDE.  a weak; b, c weak
+KG_HD void fe_sub2_wide(fe &r, const fe &a, const fe &b, const fe &c) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + fe_b4(i) - b.l[i] - c.l[i];
+}
+
+// ---- carry + fold bit 256 and above: wide -> weak ------------------------------------------
+KG_HD void fe_weak(fe &r) {
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u32 t = r.l[i] + c;  // l[i] < 2^32 - 8, c < 8
+    r.l[i] = t & M29;
+    c = t >> 29;
+  }
+  u32 t8 = r.l[8] + c;
+  u32 v = t8 >> 24;  // multiples of 2^256 -> * (2^32 + 977)
+  r.l[8] = t8 & 0xFFFFFFu;
+  r.l[0] += v * 977u;  // v < 2^8 : stays below 2^29 + 2^18
+  r.l[1] += v << 3;    // 2^32 = 8 * 2^29
+}
+
+// ---- full reduction to the canonical representative: any wide/weak -> canonical ----------
+KG_HD void fe_canon(fe &r) {
+  fe_weak(r);
+  // second carry pass (carries are 0/1 now)
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u32 t = r.l[i] + c;
+    r.l[i] = t & M29;
+    c = t >> 29;
+  }
+  r.l[8] += c;
+  // v in [0, 2^256 + eps).  Two rare cases remain: bit 256 set, or v in [p, 2^256).
+  u32 all = r.l[2] & r.l[3] & r.l[4] & r.l[5] & r.l[6] & r.l[7];
+  bool top = (r.l[8] >> 24) != 0;
+  bool maybe_ge_p = (all == M29) && (r.l[8] == 0xFFFFFFu) && (r.l[1] >= 0x1ffffff7u);
+  if (__builtin_expect(top || maybe_ge_p, 0)) {
+    // add K = 2^32 + 977; if that carries out of bit 256 then v >= p and v - p = v + K - 2^256
+    fe t = r;
+    t.l[0] += 977u;
+    t.l[1] += 8u;
+    u32 cc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      u32 s = t.l[i] + cc;
+      t.l[i] = s & M29;
+      cc = s >> 29;
+    }
+    t.l[8] += cc;
+    if (t.l[8] >> 24) {  // v + K >= 2^256  <=>  v >= p
+      t.l[8] &= 0xFFFFFFu;
+      r = t;  // v - p (v < 2p always holds here)
+    }
+  }
+}
+
+// ---- multiplication: a wide (limbs < 2^31.1, value < 2^259), b weak -> weak ----------------
+KG_HD void fe_reduce_cols(fe &r, u32 (&t)[9], u64 t9acc) {
+  // t: columns 0..8 carried to 29 bits with the fold of the high half applied;
+  // t9acc (< 2^36, because wide limbs push up to 2^34 of carry out of column 8): weight 2^261.
+  // 2^261 = R0 + R1 * 2^29 (mod p) and 2^256 = 977 + 8 * 2^29 (mod p).
+  u32 t9lo = (u32)t9acc & M29;
+  u32 t9hi = (u32)(t9acc >> 29);  // weight 2^290 = (R0 + R1 * 2^29) * 2^29
+  u32 v8 = t[8] >> 24;
+  t[8] &= 0xFFFFFFu;
+  u64 c = (u64)t[0] + (u64)(v8 * 977u) + (u64)t9lo * FE_R0;
+  r.l[0] = (u32)c & M29;
+  c >>= 29;
+  c += (u64)t[1] + (u64)(v8 << 3) + (u64)t9lo * FE_R1 + (u64)(t9hi * FE_R0);
+  r.l[1] = (u32)c & M29;
+  c >>= 29;
+  u32 cc = (u32)c + t[2] + (t9hi << 8);  // c < 2^11, t9hi < 2^7
+  r.l[2] = cc & M29;
+  cc >>= 29;
+#pragma unroll
+  for (int i = 3; i < 8; ++i) {
+    cc += t[i];
+    r.l[i] = cc & M29;
+    cc >>= 29;
+  }
+  r.l[8] = t[8] + cc;
+}
+
+KG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
+  u32 h[9], t[9];
+  u64 acc = 0;
+  // columns 9..16 (weight 2^261 and up), carried into 29-bit limbs h[0..8]
+#pragma unroll
+  for (int k = 9; k <= 16; ++k) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; ++i) acc += (u64)a.l[i] * b.l[k - i];
+    h[k - 9] = (u32)acc & M29;
+    acc >>= 29;
+  }
+  h[8] = (u32)acc;
+  // columns 0..8 plus h * (2^37 + 0x7A20)
+  acc = 0;
+#pragma unroll
+  for (int k = 0; k <= 8; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (u64)a.l[i] * b.l[k - i];
+    acc += (u64)h[k] * FE_R0;
+    if (k > 0) acc += (u64)h[k - 1] * FE_R1;
+    t[k] = (u32)acc & M29;
+    acc >>= 29;
+  }
+  acc += (u64)h[8] * FE_R1;
+  fe_reduce_cols(r, t, acc);
+}
+
+// ---- squaring: a weak -> weak ---------------------------------------------------------
+KG_HD void fe_sqr(fe &r, const fe &a) {
+  u32 h[9], t[9], d[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) d[i] = a.l[i] << 1;
+  u64 acc = 0;
+#pragma unroll
+  for (int k = 9; k <= 16; ++k) {
+#pragma unroll
+    for (int i = k - 8; 2 * i < k; ++i) acc += (u64)d[i] * a.l[k - i];
+    if ((k & 1) == 0) acc += (u64)a.l[k / 2] * a.l[k / 2];
+    h[k - 9] = (u32)acc & M29;
+    acc >>= 29;
+  }
+  h[8] = (u32)acc;
+  acc = 0;
+#pragma unroll
+  for (int k = 0; k <= 8; ++k) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; ++i) acc += (u64)d[i] * a.l[k - i];
+    if ((k & 1) == 0) acc += (u64)a.l[k / 2] * a.l[k / 2];
+    acc += (u64)h[k] * FE_R0;
+    if (k > 0) acc += (u64)h[k - 1] * FE_R1;
+    t[k] = (u32)acc & M29;
+    acc >>= 29;
+  }
+  acc += (u64)h[8] * FE_R1;
+  fe_reduce_cols(r, t, acc);
+}
+
+KG_HD bool fe_is_zero_canon(const fe &a) {
+  u32 o = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o |= a.l[i];
+  return o == 0;
+}
+
+}  // namespace kg

@@ -1,0 +1,165 @@
+// modinv30.h — constant-time modular inverse mod p for gfx950 lanes.
+//
+// Replaces the reference's data-dependent 62-bit divstep loop (math/gpu/kernel.h:565-655,
+// math/cpu/intmod.cpp:153-292), which diverges across a wavefront, with the
+// Bernstein-Yang "safegcd" iteration in the fixed-length form: 20 batches of 30 divsteps on
+// signed 30-bit limbs (600 >= the 590 divsteps proven sufficient for 256-bit inputs with the
+// delta = 1/2 start).  Every lane executes the same instruction stream, so 64 different
+// inversions cost one wave-pass.  Output: canonical a^-1 in [0,p); 0 for a = 0 (mod p) —
+// the same contract as the reference's _ModInv / Int::ModInv.
+#pragma once
+#include "fe29.h"
+
+namespace kg {
+
+constexpr i32 M30 = 0x3FFFFFFF;
+constexpr u32 P_INV30 = 0x2DDACACFu;  // p^-1 mod 2^30
+
+struct s30 {
+  i32 v[9];
+};
+struct trans2x2 {
+  i32 u, v, q, r;
+};
+
+// p = 2^256 - 2^32 - 977 in signed 30-bit limbs: {-977, -4, 0, 0, 0, 0, 0, 0, 65536}
+KG_HD i32 p30(int i) { return i == 0 ? -0x3D1 : i == 1 ? -4 : i == 8 ? 65536 : 0; }
+
+// 30 divsteps on the low words; returns the new zeta and the transition matrix (scaled 2^30)
+KG_HD i32 divsteps_30(i32 zeta, u32 f0, u32 g0, trans2x2 &t) {
+  u32 u = 1, v = 0, q = 0, r = 1;
+  u32 f = f0, g = g0;
+#pragma unroll 5
+  for (int i = 0; i < 30; ++i) {
+    u32 c1 = (u32)(zeta >> 31);     // zeta < 0
+    u32 c2 = (u32)0 - (g & 1u);     // g odd
+    u32 x = (f ^ c1) - c1;          // conditionally negated f, u, v
+    u32 y = (u ^ c1) - c1;
+    u32 z = (v ^ c1) - c1;
+    g += x & c2;
+    q += y & c2;
+    r += z & c2;
+    c1 &= c2;                       // zeta < 0 and g odd: swap roles
+    zeta = (i32)((u32)zeta ^ c1) - 1;
+    f += g & c1;
+    u += q & c1;
+    v += r & c1;
+    g >>= 1;
+    u <<= 1;
+    v <<= 1;
+  }
+  t.u = (i32)u;
+  t.v = (i32)v;
+  t.q = (i32)q;
+  t.r = (i32)r;
+  return zeta;
+}
+
+// (f,g) <- t * (f,g) / 2^30
+KG_HD void update_fg_30(s30 &f, s30 &g, const trans2x2 &t) {
+  const i64 u = t.u, v = t.v, q = t.q, r = t.r;
+  i64 cf = u * f.v[0] + v * g.v[0];
+  i64 cg = q * f.v[0] + r * g.v[0];
+  cf >>= 30;
+  cg >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    cf += u * f.v[i] + v * g.v[i];
+    cg += q * f.v[i] + r * g.v[i];
+    f.v[i - 1] = (i32)cf & M30;
+    cf >>= 30;
+    g.v[i - 1] = (i32)cg & M30;
+    cg >>= 30;
+  }
+  f.v[8] = (i32)cf;
+  g.v[8] = (i32)cg;
+}
+
+// (d,e) <- t * (d,e) / 2^30 (mod p), keeping both in (-2p, p)
+KG_HD void update_de_30(s30 &d, s30 &e, const trans2x2 &t) {
+  const i32 u = t.u, v = t.v, q = t.q, r = t.r;
+  i32 sd = d.v[8] >> 31, se = e.v[8] >> 31;
+  i32 md = (u & sd) + (v & se);
+  i32 me = (q & sd) + (r & se);
+  i64 cd = (i64)u * d.v[0] + (i64)v * e.v[0];
+  i64 ce = (i64)q * d.v[0] + (i64)r * e.v[0];
+  md -= (i32)((P_INV30 * (u32)cd + (u32)md) & (u32)M30);
+  me -= (i32)((P_INV30 * (u32)ce + (u32)me) & (u32)M30);
+  cd += (i64)p30(0) * md;
+  ce += (i64)p30(0) * me;
+  cd >>= 30;
+  ce >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    cd += (i64)u * d.v[i] + (i64)v * e.v[i];
+    ce += (i64)q * d.v[i] + (i64)r * e.v[i];
+    if (i == 1 || i == 8) {  // the only other non-zero limbs of p
+      cd += (i64)p30(i) * md;
+      ce += (i64)p30(i) * me;
+    }
+    d.v[i - 1] = (i32)cd & M30;
+    cd >>= 30;
+    e.v[i - 1] = (i32)ce & M30;
+    ce >>= 30;
+  }
+  d.v[8] = (i32)cd;
+  e.v[8] = (i32)ce;
+}
+
+// bring d from (-2p, p) into [0, p), negating first when sign < 0
+KG_HD void normalize_30(s30 &r, i32 sign) {
+  i32 cond_add = r.v[8] >> 31;
+  i32 cond_neg = sign >> 31;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    i32 x = r.v[i] + (p30(i) & cond_add);
+    r.v[i] = (x ^ cond_neg) - cond_neg;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r.v[i + 1] += r.v[i] >> 30;
+    r.v[i] &= M30;
+  }
+  cond_add = r.v[8] >> 31;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.v[i] += p30(i) & cond_add;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r.v[i + 1] += r.v[i] >> 30;
+    r.v[i] &= M30;
+  }
+}
+
+// a: any weak/wide field element.  r: canonical inverse (weak-compatible), 0 if a == 0 mod p.
+KG_HD void fe_inv(fe &r, const fe &a_in) {
+  fe a = a_in;
+  fe_canon(a);
+  s30 d, e, f, g;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    d.v[i] = 0;
+    e.v[i] = 0;
+    f.v[i] = p30(i);
+  }
+  e.v[0] = 1;
+  // 29-bit limbs -> 30-bit limbs: limb i starts at bit 30 i = 29 i + i
+#pragma unroll
+  for (int i = 0; i < 8; ++i) g.v[i] = (i32)(((a.l[i] >> i) | (a.l[i + 1] << (29 - i))) & (u32)M30);
+  g.v[8] = (i32)(a.l[8] >> 8);
+  i32 zeta = -1;
+#pragma unroll 1
+  for (int it = 0; it < 20; ++it) {
+    trans2x2 t;
+    zeta = divsteps_30(zeta, (u32)f.v[0], (u32)g.v[0], t);
+    update_de_30(d, e, t);
+    update_fg_30(f, g, t);
+  }
+  // g == 0 now, f == +-1 (or +-p when a == 0, in which case d == 0)
+  normalize_30(d, f.v[8]);
+  r.l[0] = (u32)d.v[0] & M29;
+#pragma unroll
+  for (int i = 1; i < 9; ++i)
+    r.l[i] = (((u32)d.v[i - 1] >> (30 - i)) | ((u32)d.v[i] << i)) & M29;
+}
+
+}  // namespace kg

@@ -1,0 +1,113 @@
+"""GPU parity tests: the HIP engine, driven through the C ABI, against the oracle on the same seeded
+herd and jump table.  Bit-exact: DP multiset (kIdx, x, distance), and the whole herd state."""
+import os
+
+import numpy as np
+import pytest
+
+import kgoracle as K
+from gpu_common import dp_multiset, make_case, oracle_dps
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(groups, per_group, case, nb_run=None, k=None):
+    from kangaroo_amd import GPUEngine
+
+    if k is not None:
+        os.environ["KG_K"] = str(k)
+    try:
+        e = GPUEngine(groups, per_group, 0, 65536 * 2)
+    finally:
+        os.environ.pop("KG_K", None)
+    e.SetWildOffset(case["width"] >> 1)  # core/kangaroo.cpp:436
+    e.SetParams(case["dp_mask"], case["jd"], case["jx"], case["jy"])
+    if nb_run:
+        e.SetNbRun(nb_run)
+    e.SetKangaroos(case["px"], case["py"], case["d"])
+    return e
+
+
+@pytest.mark.parametrize("k", [1, 4, 8, 12, 16])
+def test_dp_stream_and_state_match_oracle(k):
+    """BASELINE config 2 in miniature: 64-bit range, same seed -> same DPs as the CPU walk."""
+    case = make_case(64, 128 * 2 * 32, seed=1000 + k, dp_bits=6)
+    e = _engine(2, 32, case, nb_run=64, k=k)
+    assert e.KernelInfo()["k_per_lane"] == k
+    px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
+    e.callKernel()
+    for launch in range(3):
+        got = dp_multiset(e.Launch())
+        ref = oracle_dps(case, px, py, d, 64)
+        assert len(ref) > 50
+        assert got == ref, f"launch {launch}"
+    # the 4th launch is in flight; GetKangaroos waits for it
+    oracle_dps(case, px, py, d, 64)
+    gx, gy, gd = e.GetKangaroos()
+    assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
+    e.close()
+
+
+def test_default_nb_run_256_and_125_bit_range():
+    """NB_RUN = 256 (constants.h:21) with the benchmark's 125-bit jump table (3-word distance delta)."""
+    case = make_case(125, 128 * 1 * 64, seed=77, dp_bits=8)
+    e = _engine(1, 64, case)
+    px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
+    e.callKernel()
+    got = dp_multiset(e.Collect())
+    ref = oracle_dps(case, px, py, d, 256)
+    assert got == ref and len(ref) > 1000
+    gx, gy, gd = e.GetKangaroos()
+    assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
+    e.close()
+
+
+def test_wide_jump_distances_use_full_width_delta():
+    """Jump distances wider than 96 bits select the 8-word delta kernel; distances stay exact."""
+    case = make_case(250, 128 * 1 * 64, seed=5, dp_bits=5)
+    e = _engine(1, 64, case, nb_run=32)
+    assert e.KernelInfo()["delta_words"] == 8
+    px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
+    e.callKernel()
+    got = dp_multiset(e.Collect())
+    ref = oracle_dps(case, px, py, d, 32)
+    assert got == ref and len(ref) > 100
+    e.close()
+
+
+def test_set_kangaroo_between_launches():
+    """SetKangaroo (dead-kangaroo reset, core/kangaroo.cpp:484-485) lands before the next launch."""
+    case = make_case(64, 128 * 1 * 64, seed=9, dp_bits=4)
+    e = _engine(1, 64, case, nb_run=16)
+    px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
+    e.callKernel()
+    items = e.Launch()  # launch 2 already queued
+    assert dp_multiset(items) == oracle_dps(case, px, py, d, 16)
+    # replace kangaroos 5 (wild) and 8 (tame) with fresh ones while launch 2 is in flight
+    nx, ny, nd = K.create_herd(case["rng"], 64, case["width"], case["key"], 2, 1)
+    e.SetKangaroo(5, nx[0], ny[0], nd[0])
+    e.SetKangaroo(8, nx[1], ny[1], nd[1])
+    ref2 = oracle_dps(case, px, py, d, 16)  # launch 2 ran on the old herd
+    assert dp_multiset(e.Launch()) == ref2
+    px[5], py[5], d[5] = nx[0], ny[0], nd[0]
+    px[8], py[8], d[8] = nx[1], ny[1], nd[1]
+    assert dp_multiset(e.Launch()) == oracle_dps(case, px, py, d, 16)  # launch 3 sees the new ones
+    e.close()
+
+
+def test_dp_zero_bits_every_point_and_overflow_report():
+    """dpSize = 0: every jump is a DP (core/kangaroo.cpp:110-120).  Capacity overflow is reported, not hidden."""
+    from kangaroo_amd import KgError
+
+    case = make_case(64, 128 * 1 * 64, seed=3, dp_bits=0)
+    e = _engine(1, 64, case, nb_run=2)
+    px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
+    e.callKernel()
+    assert dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 2)
+    assert len(oracle_dps(case, px.copy(), py.copy(), d.copy(), 1)) == 8192
+    e.SetNbRun(64)  # 8192 * 64 = 524288 DPs > capacity 131072
+    e.callKernel()
+    with pytest.raises(KgError) as ei:
+        e.Collect()
+    assert "items lost" in str(ei.value) and e.lost == 8192 * 64 - 131072
+    e.close()
