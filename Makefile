@@ -2,13 +2,23 @@
 #   make            -> kangaroo_amd/libkangaroo_amd.so (HIP, gfx950) + oracle/libkgoracle.so
 #   make ref        -> oracle/_ref (reference CPU sources compiled in place; needs /root/reference)
 HIPCC    ?= hipcc
-HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-command-line-argument
+CXX      ?= g++
+HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument
 CSRC     := kangaroo_amd/csrc
+BUILD    := build
 
 all: kangaroo_amd/libkangaroo_amd.so oracle
 
-kangaroo_amd/libkangaroo_amd.so: $(CSRC)/engine_capi.hip $(CSRC)/walk_kernel.h $(CSRC)/fe29.h $(CSRC)/modinv30.h include/kangaroo_amd.h
-	$(HIPCC) $(HIPFLAGS) -o $@ $(CSRC)/engine_capi.hip
+$(BUILD)/engine_capi.o: $(CSRC)/engine_capi.hip $(CSRC)/walk_kernel.h $(CSRC)/fe29.h $(CSRC)/modinv30.h include/kangaroo_amd.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/engine_capi.hip
+
+$(BUILD)/host_secp.o: $(CSRC)/host_secp.cpp $(CSRC)/fe29.h $(CSRC)/modinv30.h include/kangaroo_amd.h include/kangaroo_amd_host.h
+	@mkdir -p $(BUILD)
+	$(CXX) -O2 -std=c++17 -fPIC -c -o $@ $(CSRC)/host_secp.cpp
+
+kangaroo_amd/libkangaroo_amd.so: $(BUILD)/engine_capi.o $(BUILD)/host_secp.o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^ -lpthread
 
 oracle:
 	$(MAKE) -C oracle all
@@ -17,7 +27,7 @@ ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -f kangaroo_amd/libkangaroo_amd.so
+	rm -rf $(BUILD) kangaroo_amd/libkangaroo_amd.so
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle ref clean

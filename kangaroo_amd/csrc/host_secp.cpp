@@ -1,0 +1,697 @@
+// host_secp.cpp — host-side secp256k1 set-up and DP bookkeeping (include/kangaroo_amd_host.h).
+//
+// Product code (not the oracle): what the reference does on the CPU around the GPU engine —
+// jump-table and herd creation (core/kangaroo.cpp:521-626), public-key parsing
+// (math/secp256k1.cpp:109-168), the DP table and collision resolution
+// (memory/hashtable.cpp:65-226, core/kangaroo.cpp:155-256) — written from scratch on
+// 4x64-bit limbs with unsigned __int128, always fully reduced.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <cmath>
+#include <mutex>
+#include <random>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/kangaroo_amd.h"
+#include "../../include/kangaroo_amd_host.h"
+#include "fe29.h"
+#include "modinv30.h"
+
+namespace {
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+
+struct U256 {
+  u64 v[4];
+};
+
+const U256 FP = {{0xFFFFFFFEFFFFFC2FULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL}};
+const U256 ORD = {{0xBFD25E8CD0364141ULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFEULL, 0xFFFFFFFFFFFFFFFFULL}};
+const U256 G_X = {{0x59F2815B16F81798ULL, 0x029BFCDB2DCE28D9ULL, 0x55A06295CE870B07ULL, 0x79BE667EF9DCBBACULL}};
+const U256 G_Y = {{0x9C47D08FFB10D4B8ULL, 0xFD17B448A6855419ULL, 0x5DA4FBFC0E1108A8ULL, 0x483ADA7726A3C465ULL}};
+const u64 PK = 0x1000003D1ULL;
+
+inline U256 load(const u64 *p) {
+  U256 r;
+  memcpy(r.v, p, 32);
+  return r;
+}
+inline void store(u64 *p, const U256 &a) { memcpy(p, a.v, 32); }
+inline bool is_zero(const U256 &a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
+inline int cmp(const U256 &a, const U256 &b) {
+  for (int i = 3; i >= 0; --i)
+    if (a.v[i] != b.v[i]) return a.v[i] > b.v[i] ? 1 : -1;
+  return 0;
+}
+inline u64 add_to(U256 &r, const U256 &a, const U256 &b) {
+  u128 c = 0;
+  for (int i = 0; i < 4; ++i) {
+    c += (u128)a.v[i] + b.v[i];
+    r.v[i] = (u64)c;
+    c >>= 64;
+  }
+  return (u64)c;
+}
+inline u64 sub_to(U256 &r, const U256 &a, const U256 &b) {
+  u64 br = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 t = (u128)a.v[i] - b.v[i] - br;
+    r.v[i] = (u64)t;
+    br = (u64)(t >> 64) & 1;
+  }
+  return br;
+}
+inline int bit_length(const U256 &a) {
+  for (int i = 3; i >= 0; --i)
+    if (a.v[i]) return 64 * i + 64 - __builtin_clzll(a.v[i]);
+  return 0;
+}
+inline U256 shr(const U256 &a, int n) {  // n < 64
+  U256 r;
+  for (int i = 0; i < 4; ++i) r.v[i] = (a.v[i] >> n) | ((i < 3 && n) ? (a.v[i + 1] << (64 - n)) : 0);
+  return r;
+}
+
+// ---- generic modular add/sub (m = FP or ORD), operands < m -------------------------------------
+inline U256 mod_add(const U256 &a, const U256 &b, const U256 &m) {
+  U256 t, s;
+  u64 c = add_to(t, a, b);
+  u64 br = sub_to(s, t, m);
+  return (c || !br) ? s : t;
+}
+inline U256 mod_sub(const U256 &a, const U256 &b, const U256 &m) {
+  U256 t;
+  if (sub_to(t, a, b)) add_to(t, t, m);
+  return t;
+}
+inline U256 mod_neg(const U256 &a, const U256 &m) {
+  if (is_zero(a)) return a;
+  U256 t;
+  sub_to(t, m, a);
+  return t;
+}
+inline U256 reduce_once(const U256 &a, const U256 &m) {
+  U256 s;
+  return sub_to(s, a, m) ? a : s;
+}
+
+// ---- field multiplication, canonical result ----------------------------------------------------------
+U256 fmul(const U256 &a, const U256 &b) {
+  u64 t[8] = {0};
+  for (int i = 0; i < 4; ++i) {
+    u64 c = 0;
+    for (int j = 0; j < 4; ++j) {
+      u128 w = (u128)a.v[j] * b.v[i] + t[i + j] + c;
+      t[i + j] = (u64)w;
+      c = (u64)(w >> 64);
+    }
+    t[i + 4] = c;
+  }
+  // fold 2^256 = PK twice, then bring into [0,p)
+  u128 c = 0;
+  U256 r;
+  for (int i = 0; i < 4; ++i) {
+    c += (u128)t[4 + i] * PK + t[i];
+    r.v[i] = (u64)c;
+    c >>= 64;
+  }
+  u128 m = (u128)(u64)c * PK;
+  c = (u128)r.v[0] + (u64)m;
+  r.v[0] = (u64)c;
+  c >>= 64;
+  c += (u128)r.v[1] + (u64)(m >> 64);
+  r.v[1] = (u64)c;
+  c >>= 64;
+  c += r.v[2];
+  r.v[2] = (u64)c;
+  c >>= 64;
+  c += r.v[3];
+  r.v[3] = (u64)c;
+  c >>= 64;
+  if ((u64)c) {  // one more 2^256
+    U256 k = {{PK, 0, 0, 0}};
+    add_to(r, r, k);
+  }
+  return reduce_once(r, FP);
+}
+inline U256 fsqr(const U256 &a) { return fmul(a, a); }
+inline U256 fadd(const U256 &a, const U256 &b) { return mod_add(a, b, FP); }
+inline U256 fsub(const U256 &a, const U256 &b) { return mod_sub(a, b, FP); }
+
+// inversion through the engine's own constant-time safegcd (modinv30.h)
+U256 finv(const U256 &a) {
+  uint32_t w[8];
+  for (int i = 0; i < 4; ++i) {
+    w[2 * i] = (uint32_t)a.v[i];
+    w[2 * i + 1] = (uint32_t)(a.v[i] >> 32);
+  }
+  kg::fe f, r;
+  kg::fe_from_words(f, w);
+  kg::fe_inv(r, f);
+  kg::fe_canon(r);
+  kg::fe_to_words(w, r);
+  U256 o;
+  for (int i = 0; i < 4; ++i) o.v[i] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
+  return o;
+}
+
+// in-place batch inversion (Montgomery), zero entries are left as zero
+void batch_inv(std::vector<U256> &v) {
+  const size_t n = v.size();
+  std::vector<U256> pre(n);
+  U256 acc = {{1, 0, 0, 0}};
+  for (size_t i = 0; i < n; ++i) {
+    pre[i] = acc;
+    if (!is_zero(v[i])) acc = fmul(acc, v[i]);
+  }
+  U256 inv = finv(acc);
+  for (size_t i = n; i-- > 0;) {
+    if (is_zero(v[i])) continue;
+    U256 t = fmul(inv, pre[i]);
+    inv = fmul(inv, v[i]);
+    v[i] = t;
+  }
+}
+
+// ---- points -------------------------------------------------------------------------------------------------
+struct Aff {
+  U256 x, y;
+  bool inf;
+};
+struct Jac {
+  U256 x, y, z;
+  bool inf;
+};
+
+Aff aff_add(const Aff &p, const Aff &q);
+Aff aff_dbl(const Aff &p) {
+  if (p.inf || is_zero(p.y)) return Aff{{}, {}, true};
+  U256 xx = fsqr(p.x);
+  U256 num = fadd(fadd(xx, xx), xx);
+  U256 s = fmul(num, finv(fadd(p.y, p.y)));
+  U256 rx = fsub(fsub(fsqr(s), p.x), p.x);
+  U256 ry = fsub(fmul(s, fsub(p.x, rx)), p.y);
+  return Aff{rx, ry, false};
+}
+Aff aff_add(const Aff &p, const Aff &q) {
+  if (p.inf) return q;
+  if (q.inf) return p;
+  if (cmp(p.x, q.x) == 0) {
+    if (cmp(p.y, q.y) == 0) return aff_dbl(p);
+    return Aff{{}, {}, true};
+  }
+  U256 s = fmul(fsub(q.y, p.y), finv(fsub(q.x, p.x)));
+  U256 rx = fsub(fsub(fsqr(s), p.x), q.x);
+  U256 ry = fsub(fmul(s, fsub(p.x, rx)), p.y);
+  return Aff{rx, ry, false};
+}
+
+// Jacobian doubling / mixed addition (a = 0 curve)
+Jac jac_dbl(const Jac &p) {
+  if (p.inf || is_zero(p.y)) return Jac{{}, {}, {}, true};
+  U256 a = fsqr(p.x), b = fsqr(p.y), c = fsqr(b);
+  U256 t = fadd(p.x, b);
+  U256 d = fsub(fsub(fsqr(t), a), c);
+  d = fadd(d, d);
+  U256 e = fadd(fadd(a, a), a);
+  U256 f = fsqr(e);
+  Jac r;
+  r.inf = false;
+  r.x = fsub(f, fadd(d, d));
+  U256 c8 = fadd(c, c);
+  c8 = fadd(c8, c8);
+  c8 = fadd(c8, c8);
+  r.y = fsub(fmul(e, fsub(d, r.x)), c8);
+  U256 yz = fmul(p.y, p.z);
+  r.z = fadd(yz, yz);
+  return r;
+}
+Jac jac_add_mixed(const Jac &p, const Aff &q) {
+  if (q.inf) return p;
+  if (p.inf) return Jac{q.x, q.y, {{1, 0, 0, 0}}, false};
+  U256 z2 = fsqr(p.z);
+  U256 u2 = fmul(q.x, z2);
+  U256 s2 = fmul(q.y, fmul(z2, p.z));
+  U256 h = fsub(u2, p.x);
+  U256 rr = fsub(s2, p.y);
+  if (is_zero(h)) {
+    if (is_zero(rr)) return jac_dbl(p);
+    return Jac{{}, {}, {}, true};
+  }
+  U256 h2 = fsqr(h), h3 = fmul(h2, h), v = fmul(p.x, h2);
+  Jac r;
+  r.inf = false;
+  r.x = fsub(fsub(fsqr(rr), h3), fadd(v, v));
+  r.y = fsub(fmul(rr, fsub(v, r.x)), fmul(p.y, h3));
+  r.z = fmul(p.z, h);
+  return r;
+}
+
+// fixed-base table: T[i][j] = (j+1) * 256^i * G, i < 32, j < 255 (same shape as Secp256K1::Init)
+std::vector<Aff> g_table;
+std::once_flag g_table_once;
+void build_table() {
+  g_table.resize(32 * 255);
+  Aff base{G_X, G_Y, false};
+  for (int i = 0; i < 32; ++i) {
+    Aff cur = base;
+    for (int j = 0; j < 255; ++j) {
+      g_table[i * 255 + j] = cur;
+      cur = aff_add(cur, base);
+    }
+    base = cur;  // 256 * base
+  }
+}
+
+Jac mul_g_jac(const U256 &k) {
+  std::call_once(g_table_once, build_table);
+  Jac acc{{}, {}, {}, true};
+  for (int i = 0; i < 32; ++i) {
+    unsigned b = (unsigned)((k.v[i >> 3] >> ((i & 7) * 8)) & 0xFF);
+    if (b) acc = jac_add_mixed(acc, g_table[i * 255 + (b - 1)]);
+  }
+  return acc;
+}
+Aff to_affine(const Jac &p) {
+  if (p.inf) return Aff{{}, {}, true};
+  U256 zi = finv(p.z), zi2 = fsqr(zi);
+  return Aff{fmul(p.x, zi2), fmul(p.y, fmul(zi2, zi)), false};
+}
+Aff mul_g(const U256 &k) { return to_affine(mul_g_jac(k)); }
+
+void mul_g_batch(const u64 *k, size_t n, u64 *x, u64 *y) {
+  std::vector<Jac> pts(n);
+  std::vector<U256> zs(n);
+  for (size_t i = 0; i < n; ++i) {
+    pts[i] = mul_g_jac(load(k + 4 * i));
+    zs[i] = pts[i].inf ? U256{{0, 0, 0, 0}} : pts[i].z;
+  }
+  batch_inv(zs);
+  for (size_t i = 0; i < n; ++i) {
+    U256 ox = {{0, 0, 0, 0}}, oy = {{0, 0, 0, 0}};
+    if (!pts[i].inf) {
+      U256 zi2 = fsqr(zs[i]);
+      ox = fmul(pts[i].x, zi2);
+      oy = fmul(pts[i].y, fmul(zi2, zs[i]));
+    }
+    store(x + 4 * i, ox);
+    store(y + 4 * i, oy);
+  }
+}
+
+// y from x: y^2 = x^3 + 7, p = 3 mod 4
+bool lift_x(const U256 &x, bool odd, U256 &y) {
+  U256 seven = {{7, 0, 0, 0}};
+  U256 rhs = fadd(fmul(fsqr(x), x), seven);
+  // exponent (p+1)/4
+  U256 e;
+  U256 one = {{1, 0, 0, 0}};
+  add_to(e, FP, one);
+  e = shr(e, 2);
+  U256 acc = one, base = rhs;
+  for (int bit = 0; bit < 256; ++bit) {
+    if ((e.v[bit >> 6] >> (bit & 63)) & 1) acc = fmul(acc, base);
+    base = fsqr(base);
+  }
+  if (cmp(fsqr(acc), rhs) != 0) return false;
+  if (((acc.v[0] & 1) != 0) != odd) acc = mod_neg(acc, FP);
+  y = acc;
+  return true;
+}
+
+// Int::Rand(nbit): nbit/32 words then one masked word (math/cpu/int.cpp:717-730)
+U256 rand_bits(std::mt19937 &g, int nbit) {
+  uint32_t w[10] = {0};
+  uint32_t nb = (uint32_t)nbit / 32, left = (uint32_t)nbit % 32, i = 0;
+  for (; i < nb; ++i) w[i] = (uint32_t)g();
+  w[i] = (uint32_t)g() & ((1u << left) - 1u);
+  U256 r;
+  for (int k = 0; k < 4; ++k) r.v[k] = (u64)w[2 * k] | ((u64)w[2 * k + 1] << 32);
+  return r;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int kgh_ec_mul_g(uint64_t x[4], uint64_t y[4], const uint64_t k[4]) {
+  Aff p = mul_g(load(k));
+  if (p.inf) {
+    memset(x, 0, 32);
+    memset(y, 0, 32);
+    return 0;
+  }
+  store(x, p.x);
+  store(y, p.y);
+  return 1;
+}
+int kgh_ec_mul_g_batch(uint64_t *x, uint64_t *y, const uint64_t *k, size_t n) {
+  mul_g_batch(k, n, x, y);
+  return 0;
+}
+int kgh_ec_add(uint64_t rx[4], uint64_t ry[4], const uint64_t x1[4], const uint64_t y1[4], const uint64_t x2[4],
+               const uint64_t y2[4]) {
+  Aff r = aff_add(Aff{load(x1), load(y1), false}, Aff{load(x2), load(y2), false});
+  if (r.inf) return -1;
+  store(rx, r.x);
+  store(ry, r.y);
+  return 0;
+}
+
+int kgh_parse_pubkey(const char *hex, uint64_t x[4], uint64_t y[4]) {
+  if (!hex) return -1;
+  size_t len = strlen(hex);
+  auto hv = [](char c) -> int {
+    if (c >= '0' && c <= '9') return c - '0';
+    if (c >= 'a' && c <= 'f') return 10 + c - 'a';
+    if (c >= 'A' && c <= 'F') return 10 + c - 'A';
+    return -1;
+  };
+  if (len != 66 && len != 130) return -1;
+  std::vector<uint8_t> b(len / 2);
+  for (size_t i = 0; i < len / 2; ++i) {
+    int h = hv(hex[2 * i]), l = hv(hex[2 * i + 1]);
+    if (h < 0 || l < 0) return -1;
+    b[i] = (uint8_t)(h * 16 + l);
+  }
+  auto be = [&](size_t off) {
+    U256 r = {{0, 0, 0, 0}};
+    for (int i = 0; i < 32; ++i) r.v[3 - i / 8] |= (u64)b[off + i] << (8 * (7 - i % 8));
+    return r;
+  };
+  U256 px = be(1), py;
+  if ((b[0] == 2 || b[0] == 3) && len == 66) {
+    if (cmp(px, FP) >= 0 || !lift_x(px, b[0] == 3, py)) return -2;
+  } else if (b[0] == 4 && len == 130) {
+    py = be(33);
+    U256 seven = {{7, 0, 0, 0}};
+    if (cmp(px, FP) >= 0 || cmp(py, FP) >= 0 || cmp(fsqr(py), fadd(fmul(fsqr(px), px), seven)) != 0) return -2;
+  } else {
+    return -1;
+  }
+  store(x, px);
+  store(y, py);
+  return 0;
+}
+
+int kgh_create_jump_table(int range_power, uint64_t *jd, uint64_t *jpx, uint64_t *jpy) {
+  const int jump_bit = range_power / 2 + 1;
+  const double max_avg = std::pow(2.0, (double)jump_bit - 0.95), min_avg = std::pow(2.0, (double)jump_bit - 1.05);
+  std::mt19937 g(0x600DCAFEu);
+  int tries = 0;
+  bool ok = false;
+  while (!ok && tries < 100) {
+    double sum = 0.0;
+    // the reference sums the 64 distances exactly and converts once (Int::ToDouble)
+    U256 total = {{0, 0, 0, 0}};
+    for (int i = 0; i < KG_NB_JUMP; ++i) {
+      U256 d = rand_bits(g, jump_bit);
+      if (is_zero(d)) d.v[0] = 1;
+      store(jd + 4 * i, d);
+      add_to(total, total, d);
+    }
+    double base = 1.0;
+    for (int i = 0; i < 8; ++i) {
+      sum += (double)(uint32_t)(total.v[i >> 1] >> ((i & 1) * 32)) * base;
+      base *= 4294967296.0;
+    }
+    const double avg = sum / (double)KG_NB_JUMP;
+    ok = avg > min_avg && avg < max_avg;
+    ++tries;
+  }
+  mul_g_batch(jd, KG_NB_JUMP, jpx, jpy);
+  return tries;
+}
+
+struct kgh_rng {
+  std::mt19937 g;
+};
+kgh_rng *kgh_rng_new(uint32_t seed) {
+  kgh_rng *r = new kgh_rng();
+  r->g.seed(seed);
+  return r;
+}
+void kgh_rng_free(kgh_rng *r) { delete r; }
+uint32_t kgh_rng_next(kgh_rng *r) { return (uint32_t)r->g(); }
+
+int kgh_create_herd(kgh_rng *r, int range_power, const uint64_t range_width[4], const uint64_t key_x[4],
+                    const uint64_t key_y[4], int first_type, size_t n, uint64_t *px, uint64_t *py, uint64_t *d) {
+  if (!r || !px || !py || !d) return -1;
+  const U256 w8 = shr(load(range_width), 3);
+  const int off = first_type % 2;
+  for (size_t j = 0; j < n; ++j) {
+    U256 v;
+    if (((j + (size_t)off) % 2) == 0) {
+      v = rand_bits(r->g, range_power);
+      // reference leaves the raw Rand() value (may exceed n only for 256-bit ranges)
+    } else {
+      v = rand_bits(r->g, range_power - 2);
+      v = mod_sub(v, w8, ORD);
+    }
+    store(d + 4 * j, v);
+  }
+  mul_g_batch(d, n, px, py);
+  // wild kangaroos start at key + d*G: one batched inversion over the wild subset
+  const Aff key{load(key_x), load(key_y), false};
+  if (is_zero(key.x)) return 0;
+  std::vector<size_t> idx;
+  std::vector<U256> dx;
+  for (size_t j = 0; j < n; ++j)
+    if (((j + (size_t)off) % 2) != 0) {
+      idx.push_back(j);
+      dx.push_back(fsub(load(px + 4 * j), key.x));
+    }
+  batch_inv(dx);
+  for (size_t t = 0; t < idx.size(); ++t) {
+    const size_t j = idx[t];
+    const U256 x2 = load(px + 4 * j), y2 = load(py + 4 * j);
+    const U256 s = fmul(fsub(y2, key.y), dx[t]);
+    const U256 rx = fsub(fsub(fsqr(s), key.x), x2);
+    const U256 ry = fsub(fmul(s, fsub(x2, rx)), y2);
+    store(px + 4 * j, rx);
+    store(py + 4 * j, ry);
+  }
+  return 0;
+}
+
+int kgh_synthetic_herd(const uint64_t d0[4], const uint64_t stride[4], size_t n, uint64_t *px, uint64_t *py,
+                       uint64_t *d) {
+  if (!n) return 0;
+  const size_t chains = n < 4096 ? n : 4096;
+  const U256 st = reduce_once(load(stride), ORD);
+  // heads: d0 + c*stride
+  std::vector<U256> hd(chains);
+  U256 cur = reduce_once(load(d0), ORD);
+  for (size_t c = 0; c < chains; ++c) {
+    hd[c] = cur;
+    cur = mod_add(cur, st, ORD);
+  }
+  // row step = chains * stride
+  U256 row = {{0, 0, 0, 0}};
+  for (size_t c = 0; c < chains; ++c) row = mod_add(row, st, ORD);
+  const Aff S = mul_g(row);
+  std::vector<u64> hk(4 * chains), hx(4 * chains), hy(4 * chains);
+  for (size_t c = 0; c < chains; ++c) store(&hk[4 * c], hd[c]);
+  mul_g_batch(hk.data(), chains, hx.data(), hy.data());
+  std::vector<U256> X(chains), Y(chains), dx(chains);
+  for (size_t c = 0; c < chains; ++c) {
+    X[c] = load(&hx[4 * c]);
+    Y[c] = load(&hy[4 * c]);
+  }
+  for (size_t base = 0; base < n; base += chains) {
+    const size_t cnt = (n - base) < chains ? (n - base) : chains;
+    for (size_t c = 0; c < cnt; ++c) {
+      store(px + 4 * (base + c), X[c]);
+      store(py + 4 * (base + c), Y[c]);
+      store(d + 4 * (base + c), hd[c]);
+    }
+    if (base + chains >= n) break;
+    for (size_t c = 0; c < chains; ++c) dx[c] = fsub(S.x, X[c]);
+    batch_inv(dx);
+    for (size_t c = 0; c < chains; ++c) {
+      const U256 s = fmul(fsub(S.y, Y[c]), dx[c]);
+      const U256 rx = fsub(fsub(fsqr(s), X[c]), S.x);
+      Y[c] = fsub(fmul(s, fsub(X[c], rx)), Y[c]);
+      X[c] = rx;
+      hd[c] = mod_add(hd[c], row, ORD);
+    }
+  }
+  return 0;
+}
+
+// ---- DP table ---------------------------------------------------------------------------------------------
+struct Key128 {
+  u64 h, lo, hi;
+  bool operator==(const Key128 &o) const { return h == o.h && lo == o.lo && hi == o.hi; }
+};
+struct Key128Hash {
+  size_t operator()(const Key128 &k) const { return (size_t)(k.lo * 0x9E3779B97F4A7C15ULL ^ k.hi ^ (k.h << 40)); }
+};
+struct Entry {
+  U256 x, d;
+};
+
+struct kgh_solver {
+  U256 range_start, range_end, width, width2;
+  int range_power;
+  Aff pub, key, key_neg;
+  std::unordered_map<Key128, Entry, Key128Hash> table;
+  std::mutex mu;
+  bool found = false;
+  U256 priv;
+  u64 dead = 0;
+};
+
+static void ht_convert(const U256 &x, const U256 &d, uint32_t type, Key128 &key, Entry &e) {
+  // memory/hashtable.cpp:65-89
+  u64 sign = 0;
+  e.x = x;
+  if (d.v[3] > 0x7FFFFFFFFFFFFFFFULL) {
+    U256 nn = mod_neg(d, ORD);
+    e.d = nn;
+    e.d.v[3] &= 0x3FFFFFFFFFFFFFFFULL;
+    sign = 1ULL << 63;
+  } else {
+    e.d = d;
+    e.d.v[3] &= 0x3FFFFFFFFFFFFFFFULL;
+  }
+  e.d.v[1] |= sign;
+  e.d.v[1] |= (u64)type << 62;
+  key.h = x.v[2] & 0x3FFFF;
+  key.lo = x.v[0];
+  key.hi = x.v[1];
+}
+static void calc_dist_and_type(const U256 &D, U256 &dist, uint32_t &type) {
+  // memory/hashtable.cpp:181-191
+  type = (D.v[1] & 0x4000000000000000ULL) != 0;
+  const bool sign = (D.v[1] & 0x8000000000000000ULL) != 0;
+  dist = D;
+  dist.v[1] &= 0x3FFFFFFFFFFFFFFFULL;
+  if (sign) dist = mod_neg(dist, ORD);
+}
+
+static bool check_key(kgh_solver *s, U256 d1, U256 d2, int t) {
+  // core/kangaroo.cpp:155-181 (the reference compares points on y only, math/point.cpp:54-56; a full
+  // comparison is used here and the recovered key is verified against the public key)
+  if (t & 1) d1 = mod_neg(d1, ORD);
+  if (t & 2) d2 = mod_neg(d2, ORD);
+  U256 pk = mod_add(d1, d2, ORD);
+  Aff P = mul_g(pk);
+  if (P.inf) return false;
+  if (cmp(P.x, s->key.x) != 0) return false;
+  if (cmp(P.y, s->key.y) != 0 && cmp(P.y, s->key_neg.y) != 0) return false;
+  U256 full = mod_add(pk, reduce_once(s->range_start, ORD), ORD);
+  Aff R = mul_g(full);
+  if (R.inf || cmp(R.x, s->pub.x) != 0 || cmp(R.y, s->pub.y) != 0) {
+    // symmetric solution: -(pk) + start
+    U256 alt = mod_add(mod_neg(pk, ORD), reduce_once(s->range_start, ORD), ORD);
+    Aff R2 = mul_g(alt);
+    if (R2.inf || cmp(R2.x, s->pub.x) != 0 || cmp(R2.y, s->pub.y) != 0) return false;
+    full = alt;
+  }
+  s->priv = full;
+  s->found = true;
+  return true;
+}
+
+static int add_locked(kgh_solver *s, const U256 &x, const U256 &d, u64 k_idx) {
+  const uint32_t type = (uint32_t)(k_idx & 1);
+  Key128 key;
+  Entry e;
+  ht_convert(x, d, type, key, e);
+  auto it = s->table.find(key);
+  if (it == s->table.end()) {
+    s->table.emplace(key, e);
+    return 1;
+  }
+  if (cmp(it->second.d, e.d) == 0) {  // ADD_DUPLICATE -> treated as a dead kangaroo
+    s->dead++;
+    return 0;
+  }
+  U256 d0;
+  uint32_t t0;
+  calc_dist_and_type(it->second.d, d0, t0);
+  if (t0 == type) {  // same herd
+    s->dead++;
+    return 0;
+  }
+  const U256 &td = (t0 == 0) ? d0 : d;
+  const U256 &wd = (t0 == 0) ? d : d0;
+  for (int t = 0; t < 4; ++t)
+    if (check_key(s, td, wd, t)) return 2;
+  s->dead++;  // "Unexpected wrong collision, reset kangaroo" (core/kangaroo.cpp:206-223)
+  return 0;
+}
+
+kgh_solver *kgh_solver_new(const uint64_t range_start[4], const uint64_t range_end[4], const uint64_t pub_x[4],
+                           const uint64_t pub_y[4]) {
+  kgh_solver *s = new kgh_solver();
+  s->range_start = load(range_start);
+  s->range_end = load(range_end);
+  sub_to(s->width, s->range_end, s->range_start);
+  s->range_power = bit_length(s->width);  // InitRange, core/kangaroo.cpp:649-660
+  s->width2 = shr(s->width, 1);
+  s->pub = Aff{load(pub_x), load(pub_y), false};
+  if (!is_zero(s->range_start)) {  // InitSearchKey, core/kangaroo.cpp:662-674
+    Aff rs = mul_g(reduce_once(s->range_start, ORD));
+    rs.y = mod_neg(rs.y, FP);
+    s->key = aff_add(s->pub, rs);
+  } else {
+    s->key = s->pub;
+  }
+  s->key_neg = s->key;
+  s->key_neg.y = mod_neg(s->key.y, FP);
+  return s;
+}
+void kgh_solver_free(kgh_solver *s) { delete s; }
+int kgh_solver_range_power(const kgh_solver *s) { return s->range_power; }
+void kgh_solver_wild_offset(const kgh_solver *s, uint64_t out[4]) { store(out, s->width2); }
+void kgh_solver_range_width(const kgh_solver *s, uint64_t out[4]) { store(out, s->width); }
+void kgh_solver_search_key(const kgh_solver *s, uint64_t x[4], uint64_t y[4]) {
+  store(x, s->key.x);
+  store(y, s->key.y);
+}
+int kgh_solver_add(kgh_solver *s, const uint64_t x[4], const uint64_t d[4], uint64_t k_idx) {
+  std::lock_guard<std::mutex> lock(s->mu);
+  if (s->found) return 2;
+  return add_locked(s, load(x), load(d), k_idx);
+}
+int kgh_solver_add_items(kgh_solver *s, const void *items, uint32_t n, uint32_t *dead, uint32_t *n_dead) {
+  const kg_item *it = (const kg_item *)items;
+  uint32_t nd = 0;
+  int rc = 0;
+  std::lock_guard<std::mutex> lock(s->mu);  // one lock per batch, as core/kangaroo.cpp:473-476
+  for (uint32_t i = 0; i < n && !s->found; ++i) {
+    int r = add_locked(s, load(it[i].x), load(it[i].d), it[i].kIdx);
+    if (r == 0 && dead) dead[nd++] = i;
+    if (r == 2) rc = 2;
+  }
+  if (s->found) rc = 2;
+  if (n_dead) *n_dead = nd;
+  return rc;
+}
+int kgh_solver_found(const kgh_solver *s, uint64_t priv[4]) {
+  if (!s->found) return 0;
+  if (priv) store(priv, s->priv);
+  return 1;
+}
+uint64_t kgh_solver_table_size(const kgh_solver *s) { return s->table.size(); }
+uint64_t kgh_solver_dead_count(const kgh_solver *s) { return s->dead; }
+uint64_t kgh_solver_dump(const kgh_solver *s, uint64_t *out, uint64_t cap) {
+  uint64_t n = 0;
+  for (const auto &kv : s->table) {
+    if (n >= cap) break;
+    out[9 * n] = kv.first.h;
+    memcpy(out + 9 * n + 1, kv.second.x.v, 32);
+    memcpy(out + 9 * n + 5, kv.second.d.v, 32);
+    ++n;
+  }
+  return n;
+}
+
+}  // extern "C"
