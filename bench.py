@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py — kangaroo jumps/s on N MI355X GPUs (BASELINE.json metric, config 4).
+
+Workload (one GPU): range [0, 2^125-1] (rangePower 125 -> 63-bit jumps), jump table from the fixed seed
+0x600DCAFE, DP mask of 32 bits (no solve expected, DP traffic negligible), default grid 2*CUs x 128 ->
+8.4 M kangaroos per GPU, NB_RUN = 256.  A "step" is one GPUEngine::Launch = nbKangaroo * NB_RUN jumps.
+The herd is synthetic (valid curve points d_i*G, built on the host by the product's own helper) and is
+resident in HBM before the timed region starts.  N > 1: one process per GPU, disjoint herds, no
+collective in the jump path (weak scaling); torch.distributed is used for barrier / max only.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+MAD32_PER_JUMP = 416          # 5 modmul * 74 + 1 modsqr * 46, inversion excluded
+# v_mad_u64_u32: 5.0 cycles per wave64 per SIMD measured (profiles/ubench_instr_table_r01.txt)
+# -> 1024 SIMDs * 64 lanes / 5.0 cycles * 2.4 GHz
+PEAK_MAD32_PER_S = 1024 * 64 / 5.0 * 2.4e9
+STATE_BYTES_PER_KANGAROO = 192  # 96 B loaded + 96 B stored per launch
+
+
+def cpu_baseline(seconds_target=12.0):
+    """Oracle (CPU port of SolveKeyCPU's loop) on the host cores: 1024 kangaroos per thread as the
+    reference's CPU_GRP_SIZE, same 125-bit jump table.  Bounded sample; reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import kgoracle as K
+
+    cores = min(16, os.cpu_count() or 1)
+    jd, jx, jy, _ = K.create_jump_table(125)
+    rng = K.RNG(1)
+    key = K.ec_mul_g(0xA5B3C1D2E7)
+    width = (1 << 125) - 1
+    herds = [K.create_herd(rng, 125, width, key, 1024, 0) for _ in range(cores)]
+    # calibrate on one thread
+    t0 = time.time()
+    K.walk_raw(*herds[0], 20, 0xFFFFFFFF00000000, jd, jx, jy, 16)
+    per_step = (time.time() - t0) / 20
+    steps = max(50, int(seconds_target / per_step))
+
+    def work(h):
+        K.walk_raw(h[0], h[1], h[2], steps, 0xFFFFFFFF00000000, jd, jx, jy, 16)
+
+    th = [threading.Thread(target=work, args=(h,)) for h in herds]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.time() - t0
+    jumps = cores * 1024 * steps
+    return {"value": jumps / dt, "unit": "jumps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} threads x 1024 kangaroos x {steps} steps, 125-bit range, oracle/kg_oracle.c ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=str, default="", help="x,y (kangaroos = 128*x*y per GPU); default engine grid")
+    ap.add_argument("--nb-run", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from kangaroo_amd import GPUEngine, dist, host
+
+    rank, local_rank, world = dist.init()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    gpu_id = local_rank
+
+    gx, gy = (int(v) for v in args.grid.split(",")) if args.grid else (0, 0)
+    gx, gy = GPUEngine.GetGridSize(gpu_id, gx, gy)
+    eng = GPUEngine(gx, gy, gpu_id, 65536 * 2)
+    n = eng.nbKangaroo
+
+    # configuration: built on rank 0, broadcast once (6 KiB jump table + dpMask + wild offset)
+    if rank == 0:
+        jd, jx, jy, _ = host.create_jump_table(125)
+        cfg = np.concatenate([jd.reshape(-1), jx.reshape(-1), jy.reshape(-1),
+                              np.array([0xFFFFFFFF00000000], dtype=np.uint64), host.limbs(((1 << 125) - 1) >> 1)])
+    else:
+        cfg = np.zeros(64 * 4 * 3 + 1 + 4, dtype=np.uint64)
+    cfg = dist.broadcast_config(cfg)
+    jd, jx, jy = (cfg[i * 256:(i + 1) * 256].reshape(64, 4) for i in range(3))
+    dp_mask = int(cfg[768])
+    wild = cfg[769:773]
+
+    d0, stride = dist.herd_shard(rank, world, n)
+    px, py, d = host.synthetic_herd(n, d0=d0, stride=stride)
+    eng.SetWildOffset(wild)
+    eng.SetParams(dp_mask, jd, jx, jy)
+    eng.SetNbRun(args.nb_run)
+    eng.SetKangaroos(px, py, d)
+    del px, py, d
+
+    # warmup
+    eng.callKernel()
+    for _ in range(max(args.warmup - 1, 0)):
+        eng.Launch()
+    eng.Collect()
+
+    import torch
+
+    dist.barrier()
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    kernel_ms = []
+    n_dp = 0
+    t0 = time.perf_counter()
+    eng.callKernel()
+    for _ in range(args.steps - 1):
+        n_dp += len(eng.Launch())
+        kernel_ms.append(eng.LastKernelMs())
+    n_dp += len(eng.Collect())
+    kernel_ms.append(eng.LastKernelMs())
+    torch.cuda.synchronize() if torch.cuda.is_available() else None
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = dist.max_over_ranks(elapsed)
+    total_kangaroos = dist.sum_over_ranks(n)
+
+    jumps = total_kangaroos * args.nb_run * args.steps
+    value = jumps / elapsed
+    info = eng.KernelInfo()
+    avg_kernel_ms = float(np.mean(kernel_ms))
+    kernel_jumps_per_s = n * args.nb_run / (avg_kernel_ms * 1e-3)
+    achieved = kernel_jumps_per_s * MAD32_PER_JUMP
+    out = {
+        "metric": "kangaroo jumps/sec (secp256k1 affine jump incl. grouped inversion, DP test and append)",
+        "value": value, "unit": "jumps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32 limbs (9x29-bit), 64-bit accumulate", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: 125-bit range throughput, jump table seed 0x600DCAFE, DP mask 32 bits",
+                   "kangaroos_per_gpu": n, "grid": [gx, gy], "nb_run": args.nb_run,
+                   "kangaroos_per_lane": info["k_per_lane"], "delta_words": info["delta_words"],
+                   "lds_bytes_per_workgroup": info["lds_bytes"], "workgroups": info["grid"], "dps_seen": n_dp},
+        "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MAD32_PER_S / 1e12,
+                     "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_PER_S, "traffic": None,
+                     "kernel": "kg_walk_kernel", "kernel_ms_avg": avg_kernel_ms,
+                     "mad32_per_jump": MAD32_PER_JUMP, "kernel_jumps_per_s": kernel_jumps_per_s,
+                     "hbm_state_GBps": n * STATE_BYTES_PER_KANGAROO / (avg_kernel_ms * 1e-3) / 1e9,
+                     "note": "bound is VALU integer multiply issue (SURVEY §8d), not HBM/MFMA; HBM traffic is 0.75 B/jump"},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
