@@ -21,6 +21,7 @@
 
 #include "../../include/kangaroo_amd.h"
 #include "walk_kernel.h"
+#include "walk_kernel_rot.h"
 
 using namespace kg;
 
@@ -109,18 +110,30 @@ struct kg_engine {
 // ---- kernel dispatch ------------------------------------------------------------------------
 typedef void (*walk_fn)(WalkArgs);
 struct Variant {
-  int K, DW;
+  int K, DW, W, U;  // U = 0: fully unrolled kernel; U > 0: rotating-window kernel with a window of U
   walk_fn fn;
 };
-#define KG_VARIANT(K, DW) {K, DW, kg_walk_kernel<K, DW>}
+#define KG_VARIANT(K, DW, W) {K, DW, W, 0, kg_walk_kernel<K, DW, W>}
+#define KG_VARIANT_ROT(K, U, DW, W) {K, DW, W, U, kg_walk_kernel_rot<K, U, DW, W>}
 static const Variant g_variants[] = {
-    KG_VARIANT(1, 3),  KG_VARIANT(1, 8),  KG_VARIANT(4, 3),  KG_VARIANT(4, 8),  KG_VARIANT(8, 3),
-    KG_VARIANT(8, 8),  KG_VARIANT(12, 3), KG_VARIANT(12, 8), KG_VARIANT(16, 3), KG_VARIANT(16, 8),
+    KG_VARIANT(1, 3, 2),  KG_VARIANT(1, 8, 2),  KG_VARIANT(4, 3, 2),  KG_VARIANT(4, 8, 2),
+    KG_VARIANT(8, 3, 2),  KG_VARIANT(8, 8, 2),  KG_VARIANT(8, 3, 1),  KG_VARIANT(8, 8, 1),
+    KG_VARIANT(12, 3, 1), KG_VARIANT(12, 8, 1),
+    KG_VARIANT_ROT(8, 4, 3, 2),  KG_VARIANT_ROT(8, 4, 8, 2),
+    KG_VARIANT_ROT(12, 4, 3, 1), KG_VARIANT_ROT(12, 4, 8, 1),
+    KG_VARIANT_ROT(16, 4, 3, 1), KG_VARIANT_ROT(16, 4, 8, 1),
+    KG_VARIANT_ROT(16, 2, 3, 1), KG_VARIANT_ROT(16, 2, 8, 1),
 };
 
+static int env_int(const char *name, int dflt) {
+  const char *s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
 static const Variant *find_variant(int K, int DW) {
+  const int w = env_int("KG_W", 0), u = env_int("KG_U", -1);
   for (const Variant &v : g_variants)
-    if (v.K == K && v.DW == DW) return &v;
+    if (v.K == K && v.DW == DW && (w == 0 || v.W == w) && (u < 0 || v.U == u)) return &v;
   return nullptr;
 }
 
@@ -481,7 +494,7 @@ extern "C" int kg_kick(kg_engine *e) {
   a.out = e->out_dev[b];
   a.out_count = e->count_dev + b;
   a.max_found = e->max_found;
-  const size_t lds = walk_lds_bytes(e->K, e->DW);
+  const size_t lds = v->U ? walk_rot_lds_bytes(e->K, e->DW) : walk_lds_bytes(e->K, e->DW);
   if (lds > 64 * 1024)  // above the default dynamic-LDS limit (gfx950 has 160 KiB per CU)
     HIPCHK(hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipMemsetAsync(e->count_dev + b, 0, sizeof(u32), e->stream));
@@ -582,7 +595,8 @@ extern "C" int kg_kernel_info(const kg_engine *e, int *k_per_lane, int *delta_wo
   const int dw = e->params_set ? pick_delta_words(e) : e->DW;
   if (k_per_lane) *k_per_lane = e->K;
   if (delta_words) *delta_words = dw;
-  if (lds_bytes) *lds_bytes = (int)walk_lds_bytes(e->K, dw);
+  const Variant *v = find_variant(e->K, dw);
+  if (lds_bytes) *lds_bytes = (int)((v && v->U) ? walk_rot_lds_bytes(e->K, dw) : walk_lds_bytes(e->K, dw));
   if (grid) *grid = (int)e->grid;
   return KG_OK;
 }

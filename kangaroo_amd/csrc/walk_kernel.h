@@ -84,8 +84,9 @@ __device__ __forceinline__ void delta_add(u32 (&d)[DW], const u32 *jd) {
   }
 }
 
-template <int K, int DW>
-__global__ void __launch_bounds__(WALK_BLOCK) kg_walk_kernel(WalkArgs a) {
+// W = minimum waves per SIMD the register allocation must allow (1: up to 512 VGPR+AGPR, 2: 256)
+template <int K, int DW, int W>
+__global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel(WalkArgs a) {
   extern __shared__ u32 lds[];
   u32 *jt = lds;                                  // [64][JT_STRIDE]
   u32 *jdist = lds + NB_JUMP * JT_STRIDE;         // [64][DW]
@@ -125,8 +126,17 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_walk_kernel(WalkArgs a) {
     for (int i = 0; i < DW; ++i) delta[k][i] = 0;
   }
 
+  // do-while (the host guarantees nb_run >= 1): a zero-trip bypass edge would make the allocator keep a
+  // second copy of the whole loaded herd alive around the loop
+  u32 run = 0;
 #pragma unroll 1
-  for (u32 run = 0; run < a.nb_run; ++run) {
+  do {
+    // Opaque copy of the thread index for everything address-like inside the loop: without it LLVM
+    // hoists the (loop-invariant) DP-path and LDS addresses of all K kangaroos out of the loop and
+    // keeps them in registers for the whole walk.
+    u32 tidv = tid;
+    asm volatile("" : "+v"(tidv));
+    const u64 Tv = (u64)blockIdx.x * WALK_BLOCK + tidv;
     // ---- forward pass: prefix products of dx --------------------------------------------
     fe q;
     static_for<0, K>([&](auto kc) {
@@ -147,7 +157,7 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_walk_kernel(WalkArgs a) {
       }
       if constexpr (k < K - 1) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) pref[(k * 9 + i) * WALK_BLOCK + tid] = q.l[i];
+        for (int i = 0; i < 9; ++i) pref[(k * 9 + i) * WALK_BLOCK + tidv] = q.l[i];
       }
     });
     // ---- one inversion per lane -----------------------------------------------------------
@@ -168,7 +178,7 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_walk_kernel(WalkArgs a) {
       if constexpr (k > 0) {
         fe qp;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) qp.l[i] = pref[((k - 1) * 9 + i) * WALK_BLOCK + tid];
+        for (int i = 0; i < 9; ++i) qp.l[i] = pref[((k - 1) * 9 + i) * WALK_BLOCK + tidv];
         fe_sub_wide(dx, x[k], jx);
         fe_mul(dxi, qp, u);   // (q_{k-1}) * (q_k)^-1 = dx_k^-1      (both weak)
         fe_mul(u, dx, u);     // (q_k)^-1 * dx_k = (q_{k-1})^-1
@@ -192,7 +202,7 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_walk_kernel(WalkArgs a) {
       // distinguished point: (x.bits64[3] & dpMask) == 0   (math/gpu/compute.h:54)
       const u32 top_hi = (rx.l[8] << 8) | (rx.l[7] >> 21);
       const u32 top_lo = (rx.l[7] << 11) | (rx.l[6] >> 18);
-      const u64 p = T + (u64)k * a.threads;
+      const u64 p = Tv + (u64)k * a.threads;
       const bool is_dp = ((top_hi & a.dp_mask_hi) | (top_lo & a.dp_mask_lo)) == 0 && p < a.n;
       const unsigned long long m = __ballot(is_dp);
       if (m != 0) {
@@ -225,12 +235,15 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_walk_kernel(WalkArgs a) {
         }
       }
     });
-  }
+  } while (++run < a.nb_run);
 
   // ---- write the herd back ---------------------------------------------------------------------
+  u32 tidw = tid;
+  asm volatile("" : "+v"(tidw));  // keeps the store addresses from being computed (and spilled) before the loop
+  const u64 Tw = (u64)blockIdx.x * WALK_BLOCK + tidw;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const u64 p = T + (u64)k * a.threads;
+    const u64 p = Tw + (u64)k * a.threads;
     u32 w[8];
     fe_to_words(w, x[k]);  // canonical already
 #pragma unroll

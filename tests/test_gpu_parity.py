@@ -11,15 +11,17 @@ from gpu_common import dp_multiset, make_case, oracle_dps
 pytestmark = pytest.mark.gpu
 
 
-def _engine(groups, per_group, case, nb_run=None, k=None):
+def _engine(groups, per_group, case, nb_run=None, k=None, u=None, w=None):
     from kangaroo_amd import GPUEngine
 
-    if k is not None:
-        os.environ["KG_K"] = str(k)
+    for name, val in (("KG_K", k), ("KG_U", u), ("KG_W", w)):
+        if val is not None:
+            os.environ[name] = str(val)
     try:
         e = GPUEngine(groups, per_group, 0, 65536 * 2)
     finally:
-        os.environ.pop("KG_K", None)
+        for name in ("KG_K", "KG_U", "KG_W"):
+            os.environ.pop(name, None)
     e.SetWildOffset(case["width"] >> 1)  # core/kangaroo.cpp:436
     e.SetParams(case["dp_mask"], case["jd"], case["jx"], case["jy"])
     if nb_run:
@@ -28,11 +30,16 @@ def _engine(groups, per_group, case, nb_run=None, k=None):
     return e
 
 
-@pytest.mark.parametrize("k", [1, 4, 8, 12, 16])
-def test_dp_stream_and_state_match_oracle(k):
-    """BASELINE config 2 in miniature: 64-bit range, same seed -> same DPs as the CPU walk."""
+# (kangaroos per lane, window U: 0 = fully unrolled kernel, waves/SIMD the allocation allows)
+VARIANTS = [(1, 0, 2), (4, 0, 2), (8, 0, 2), (8, 0, 1), (12, 0, 1), (8, 4, 2), (12, 4, 1), (16, 4, 1), (16, 2, 1)]
+
+
+@pytest.mark.parametrize("k,u,w", VARIANTS)
+def test_dp_stream_and_state_match_oracle(k, u, w):
+    """BASELINE config 2 in miniature: 64-bit range, same seed -> same DPs as the CPU walk.
+    Odd and even step counts per launch exercise both pass directions of the rotating kernel."""
     case = make_case(64, 128 * 2 * 32, seed=1000 + k, dp_bits=6)
-    e = _engine(2, 32, case, nb_run=64, k=k)
+    e = _engine(2, 32, case, nb_run=64, k=k, u=u, w=w)
     assert e.KernelInfo()["k_per_lane"] == k
     px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
     e.callKernel()
@@ -41,8 +48,14 @@ def test_dp_stream_and_state_match_oracle(k):
         ref = oracle_dps(case, px, py, d, 64)
         assert len(ref) > 50
         assert got == ref, f"launch {launch}"
-    # the 4th launch is in flight; GetKangaroos waits for it
-    oracle_dps(case, px, py, d, 64)
+    # the 4th launch is in flight; collect it, then an odd-length launch
+    assert dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 64)
+    e.SetNbRun(7)
+    e.callKernel()
+    assert dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 7)
+    e.SetNbRun(1)
+    e.callKernel()
+    assert dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 1)
     gx, gy, gd = e.GetKangaroos()
     assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
     e.close()
