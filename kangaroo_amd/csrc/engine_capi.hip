@@ -138,12 +138,11 @@ static const Variant *find_variant(int K, int DW) {
 }
 
 static int default_k() {
-  const char *s = getenv("KG_K");  // experiment knob; the default is the measured best
-  if (s && *s) {
-    int k = atoi(s);
-    if (find_variant(k, 3)) return k;
-  }
-  return 8;
+  // KG_K / KG_U / KG_W are experiment knobs; the default (16 kangaroos per lane, window of 4,
+  // one wave per SIMD) is the measured best on MI355X (profiles/r01_variants.txt)
+  const int k = env_int("KG_K", 0);
+  if (k > 0 && (find_variant(k, 3) || find_variant(k, 8))) return k;
+  return 16;
 }
 
 static int bit_length256(const u64 v[4]) {
@@ -278,7 +277,8 @@ extern "C" int kg_create(int gpu_id, int groups, int per_group, uint32_t max_fou
   // the caller's maxFound is a hint (core/kangaroo.cpp:408); never smaller than it, and large
   // enough for one DP per kangaroo per launch up to 4M items so that low-DP runs do not drop items
   e->max_found = std::max<u32>(max_found, (u32)std::min<u64>(e->n, 1u << 22));
-  snprintf(e->name, sizeof e->name, "GPU #%d %s (%dx%d cores) Grid(%dx%d)", gpu_id, prop.name,
+  snprintf(e->name, sizeof e->name, "GPU #%d %s (%dx%d cores) Grid(%dx%d)", gpu_id,
+           prop.name[0] ? prop.name : prop.gcnArchName,
            prop.multiProcessorCount, 64 * 4, groups, per_group);
 
 #define CRT(expr)                                                                       \

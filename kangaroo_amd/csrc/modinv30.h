@@ -25,6 +25,18 @@ struct trans2x2 {
 // p = 2^256 - 2^32 - 977 in signed 30-bit limbs: {-977, -4, 0, 0, 0, 0, 0, 0, 65536}
 KG_HD i32 p30(int i) { return i == 0 ? -0x3D1 : i == 1 ? -4 : i == 8 ? 65536 : 0; }
 
+// c + a * b on signed 32-bit operands.  hipcc lowers the C expression to v_mad_u64_u32 plus v_mul_lo_u32
+// sign corrections (3 instructions per product); the hardware has the signed form.
+KG_HD i64 mad_i64(i32 a, i32 b, i64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  i64 r;
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
+  return r;
+#else
+  return c + (i64)a * b;
+#endif
+}
+
 // 30 divsteps on the low words; returns the new zeta and the transition matrix (scaled 2^30)
 KG_HD i32 divsteps_30(i32 zeta, u32 f0, u32 g0, trans2x2 &t) {
   u32 u = 1, v = 0, q = 0, r = 1;
@@ -55,17 +67,57 @@ KG_HD i32 divsteps_30(i32 zeta, u32 f0, u32 g0, trans2x2 &t) {
   return zeta;
 }
 
+// Variable-time batch of 30 divsteps (the delta = 1 form, eta = -delta): every iteration strips the
+// trailing zeros of g at once and then cancels up to 8 more low bits with one multiple of f.  Lanes
+// take different iteration counts; the loop runs until the slowest lane of the wavefront is done
+// (about 11.5 iterations against 30 fixed steps, measured), finished lanes are masked off.
+KG_HD i32 divsteps_30_var(i32 eta, u32 f0, u32 g0, trans2x2 &t) {
+  u32 u = 1, v = 0, q = 0, r = 1;
+  u32 f = f0, g = g0;
+  i32 i = 30;
+  for (;;) {
+    const u32 zeros = (u32)__builtin_ctz(g | (0xFFFFFFFFu << i));  // sentinel: never more than i
+    g >>= zeros;
+    u <<= zeros;
+    v <<= zeros;
+    eta -= (i32)zeros;
+    i -= (i32)zeros;
+    if (i == 0) break;
+    if (eta < 0) {  // swap roles: (f, g) <- (g, -f)
+      u32 tmp;
+      eta = -eta;
+      tmp = f; f = g; g = 0u - tmp;
+      tmp = u; u = q; q = 0u - tmp;
+      tmp = v; v = r; r = 0u - tmp;
+    }
+    const i32 limit = (eta + 1) > i ? i : (eta + 1);
+    const u32 m = (0xFFFFFFFFu >> (32 - limit)) & 255u;
+    // f^-1 mod 2^8 by Newton: (3f)^2 is correct to 5 bits, one step gives 10
+    u32 fi = (f * 3u) ^ 2u;
+    fi *= 2u - f * fi;
+    const u32 w = (g * (0u - fi)) & m;  // multiple of f that clears the low min(limit, 8) bits of g
+    g += f * w;
+    q += u * w;
+    r += v * w;
+  }
+  t.u = (i32)u;
+  t.v = (i32)v;
+  t.q = (i32)q;
+  t.r = (i32)r;
+  return eta;
+}
+
 // (f,g) <- t * (f,g) / 2^30
 KG_HD void update_fg_30(s30 &f, s30 &g, const trans2x2 &t) {
-  const i64 u = t.u, v = t.v, q = t.q, r = t.r;
-  i64 cf = u * f.v[0] + v * g.v[0];
-  i64 cg = q * f.v[0] + r * g.v[0];
+  const i32 u = t.u, v = t.v, q = t.q, r = t.r;  // 32-bit x 32-bit -> v_mad_i64_i32
+  i64 cf = mad_i64(u, f.v[0], mad_i64(v, g.v[0], 0));
+  i64 cg = mad_i64(q, f.v[0], mad_i64(r, g.v[0], 0));
   cf >>= 30;
   cg >>= 30;
 #pragma unroll
   for (int i = 1; i < 9; ++i) {
-    cf += u * f.v[i] + v * g.v[i];
-    cg += q * f.v[i] + r * g.v[i];
+    cf = mad_i64(u, f.v[i], mad_i64(v, g.v[i], cf));
+    cg = mad_i64(q, f.v[i], mad_i64(r, g.v[i], cg));
     f.v[i - 1] = (i32)cf & M30;
     cf >>= 30;
     g.v[i - 1] = (i32)cg & M30;
@@ -81,21 +133,25 @@ KG_HD void update_de_30(s30 &d, s30 &e, const trans2x2 &t) {
   i32 sd = d.v[8] >> 31, se = e.v[8] >> 31;
   i32 md = (u & sd) + (v & se);
   i32 me = (q & sd) + (r & se);
-  i64 cd = (i64)u * d.v[0] + (i64)v * e.v[0];
-  i64 ce = (i64)q * d.v[0] + (i64)r * e.v[0];
+  i64 cd = mad_i64(u, d.v[0], mad_i64(v, e.v[0], 0));
+  i64 ce = mad_i64(q, d.v[0], mad_i64(r, e.v[0], 0));
   md -= (i32)((P_INV30 * (u32)cd + (u32)md) & (u32)M30);
   me -= (i32)((P_INV30 * (u32)ce + (u32)me) & (u32)M30);
-  cd += (i64)p30(0) * md;
-  ce += (i64)p30(0) * me;
+  cd = mad_i64(p30(0), md, cd);
+  ce = mad_i64(p30(0), me, ce);
   cd >>= 30;
   ce >>= 30;
 #pragma unroll
   for (int i = 1; i < 9; ++i) {
-    cd += (i64)u * d.v[i] + (i64)v * e.v[i];
-    ce += (i64)q * d.v[i] + (i64)r * e.v[i];
-    if (i == 1 || i == 8) {  // the only other non-zero limbs of p
-      cd += (i64)p30(i) * md;
-      ce += (i64)p30(i) * me;
+    cd = mad_i64(u, d.v[i], mad_i64(v, e.v[i], cd));
+    ce = mad_i64(q, d.v[i], mad_i64(r, e.v[i], ce));
+    if (i == 1) {  // p30(1) = -4
+      cd -= (i64)md << 2;
+      ce -= (i64)me << 2;
+    }
+    if (i == 8) {  // p30(8) = 2^16
+      cd += (i64)md << 16;
+      ce += (i64)me << 16;
     }
     d.v[i - 1] = (i32)cd & M30;
     cd >>= 30;
@@ -131,7 +187,9 @@ KG_HD void normalize_30(s30 &r, i32 sign) {
 }
 
 // a: any weak/wide field element.  r: canonical inverse (weak-compatible), 0 if a == 0 mod p.
-KG_HD void fe_inv(fe &r, const fe &a_in) {
+// VAR = false: fixed 20 x 30 divsteps (no divergence).  VAR = true: variable-time batches until g == 0.
+template <bool VAR>
+KG_HD void fe_inv_t(fe &r, const fe &a_in) {
   fe a = a_in;
   fe_canon(a);
   s30 d, e, f, g;
@@ -147,12 +205,29 @@ KG_HD void fe_inv(fe &r, const fe &a_in) {
   for (int i = 0; i < 8; ++i) g.v[i] = (i32)(((a.l[i] >> i) | (a.l[i + 1] << (29 - i))) & (u32)M30);
   g.v[8] = (i32)(a.l[8] >> 8);
   i32 zeta = -1;
+  if (VAR) {
+    // delta = 1 variant: at most 724 divsteps (25 batches) in theory, 17-19 batches in practice
+    u32 nz = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nz |= (u32)g.v[i];
 #pragma unroll 1
-  for (int it = 0; it < 20; ++it) {
-    trans2x2 t;
-    zeta = divsteps_30(zeta, (u32)f.v[0], (u32)g.v[0], t);
-    update_de_30(d, e, t);
-    update_fg_30(f, g, t);
+    while (nz != 0) {
+      trans2x2 t;
+      zeta = divsteps_30_var(zeta, (u32)f.v[0], (u32)g.v[0], t);
+      update_de_30(d, e, t);
+      update_fg_30(f, g, t);
+      nz = 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) nz |= (u32)g.v[i];
+    }
+  } else {
+#pragma unroll 1
+    for (int it = 0; it < 20; ++it) {
+      trans2x2 t;
+      zeta = divsteps_30(zeta, (u32)f.v[0], (u32)g.v[0], t);
+      update_de_30(d, e, t);
+      update_fg_30(f, g, t);
+    }
   }
   // g == 0 now, f == +-1 (or +-p when a == 0, in which case d == 0)
   normalize_30(d, f.v[8]);
@@ -161,5 +236,10 @@ KG_HD void fe_inv(fe &r, const fe &a_in) {
   for (int i = 1; i < 9; ++i)
     r.l[i] = (((u32)d.v[i - 1] >> (30 - i)) | ((u32)d.v[i] << i)) & M29;
 }
+
+#ifndef KG_INV_VARTIME
+#define KG_INV_VARTIME 1
+#endif
+KG_HD void fe_inv(fe &r, const fe &a) { fe_inv_t<KG_INV_VARTIME != 0>(r, a); }
 
 }  // namespace kg

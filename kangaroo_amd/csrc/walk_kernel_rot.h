@@ -124,15 +124,54 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_rot(WalkArgs a) 
   reverse_fe<K>(x);
   reverse_fe<K>(y);
 
+#ifdef KG_PROFILE
+  u64 prof_inv = 0;
+  const u64 prof_start = __builtin_amdgcn_s_memtime();
+#endif
   u32 run = 0;
 #pragma unroll 1
   do {
     // registers hold the ids in processing order: id(t) = asc ? t : K-1-t, dir = asc ? +1 : -1
     const bool asc = (run & 1) != 0;
     fe u;
+#ifdef KG_PROFILE
+    const u64 tp0 = __builtin_amdgcn_s_memtime();
+#endif
     fe_inv(u, acc);
+#ifdef KG_PROFILE
+    const u64 tp1 = __builtin_amdgcn_s_memtime();
+    prof_inv += tp1 - tp0;
+#endif
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc.l[i] = (i == 0);
+
+    // Software prefetch: the jump-table row and the stored partial product of kangaroo t+1 are read
+    // from LDS while kangaroo t is being computed (one wave per SIMD has nothing else to hide the
+    // LDS latency behind).  cur = operands of the kangaroo about to be processed.
+    struct Pre {
+      fe jx, jy, qp;
+      u32 jmp;
+    };
+    auto prefetch = [&](Pre &pr, const fe &xs, int t, u32 tv) {
+      pr.jmp = xs.l[0] & (NB_JUMP - 1);
+      const u32 *row = jt + pr.jmp * JT_STRIDE;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        pr.jx.l[i] = row[i];
+        pr.jy.l[i] = row[9 + i];
+      }
+      const int idn = asc ? t : K - 1 - t;
+      int nb = asc ? idn + 1 : idn - 1;  // the id processed after this one; clamped for the last (unused there)
+      nb = nb < 0 ? 0 : (nb > K - 1 ? K - 1 : nb);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pr.qp.l[i] = pref[(nb * 9 + i) * WALK_BLOCK + tv];
+    };
+    Pre cur;
+    {
+      u32 tv0 = tid;
+      asm volatile("" : "+v"(tv0));
+      prefetch(cur, x[0], 0, tv0);
+    }
 
 #pragma unroll 1
     for (int blk = 0; blk < K / U; ++blk) {
@@ -144,22 +183,17 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_rot(WalkArgs a) 
         __builtin_amdgcn_sched_barrier(0);
         const int t = blk * U + j;
         const int id = asc ? t : K - 1 - t;
-        const u32 jmp = x[j].l[0] & (NB_JUMP - 1);
-        const u32 *row = jt + jmp * JT_STRIDE;
-        fe jx, jy, dx, dxi;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          jx.l[i] = row[i];
-          jy.l[i] = row[9 + i];
-        }
+        // issue the loads for the next kangaroo first (slot j+1; slot U is the first of the next block)
+        Pre nxt;
+        prefetch(nxt, x[(j + 1) % K], t + 1 < K ? t + 1 : K - 1, tidv);
+        __builtin_amdgcn_sched_barrier(0);
+        const u32 jmp = cur.jmp;
+        const fe jx = cur.jx, jy = cur.jy;
+        fe dx, dxi;
         // dx_id^-1 = u * (product of the ids still to come in this pass)
         if (t < K - 1) {
-          const int nb = asc ? id + 1 : id - 1;
-          fe qp;
-#pragma unroll
-          for (int i = 0; i < 9; ++i) qp.l[i] = pref[(nb * 9 + i) * WALK_BLOCK + tidv];
           fe_sub_wide(dx, x[j], jx);
-          fe_mul(dxi, qp, u);
+          fe_mul(dxi, cur.qp, u);
           fe_mul(u, dx, u);
         } else {
           dxi = u;
@@ -217,6 +251,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_rot(WalkArgs a) 
             }
           }
         }
+        cur = nxt;
       });
       rot_left_fe<K, U>(x);
       rot_left_fe<K, U>(y);
@@ -241,6 +276,11 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_rot(WalkArgs a) 
     }
   } while (++run < a.nb_run);
 
+#ifdef KG_PROFILE
+  if (blockIdx.x == 0 && (tid & 63) == 0)
+    printf("[kg profile] wave %u: loop %llu cycles, inversion %llu cycles (%u steps)\n", tid >> 6,
+           (unsigned long long)(__builtin_amdgcn_s_memtime() - prof_start), (unsigned long long)prof_inv, a.nb_run);
+#endif
   // ---- write the herd back: slot s holds id s if the last pass was descending (it ended with a reversal) ----
   const bool natural = ((a.nb_run - 1) & 1) == 0;
   u32 tidw = tid;

@@ -35,7 +35,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(_HERE, "libkangaroo_amd.so")
+    # KANGAROO_AMD_LIB: alternative build of the same library (A/B measurements)
+    return os.environ.get("KANGAROO_AMD_LIB") or os.path.join(_HERE, "libkangaroo_amd.so")
 
 
 def load_library():
