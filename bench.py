@@ -135,6 +135,16 @@ def main():
     avg_kernel_ms = float(np.mean(kernel_ms))
     kernel_jumps_per_s = n * args.nb_run / (avg_kernel_ms * 1e-3)
     achieved = kernel_jumps_per_s * MAD32_PER_JUMP
+    # HBM bytes per launch from the PMC passes of the same command (FETCH_SIZE + WRITE_SIZE, see
+    # profiles/r01_pmc_hbm.json and DESIGN.md "Measurement"); only quoted when the launch shape is the one profiled
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
+            pmc = json.load(f)
+        if pmc["kangaroos_per_gpu"] == n and pmc["nb_run"] == args.nb_run:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "kangaroo jumps/sec (secp256k1 affine jump incl. grouped inversion, DP test and append)",
         "value": value, "unit": "jumps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -145,8 +155,8 @@ def main():
                    "kangaroos_per_lane": info["k_per_lane"], "delta_words": info["delta_words"],
                    "lds_bytes_per_workgroup": info["lds_bytes"], "workgroups": info["grid"], "dps_seen": n_dp},
         "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MAD32_PER_S / 1e12,
-                     "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_PER_S, "traffic": None,
-                     "kernel": "kg_walk_kernel", "kernel_ms_avg": avg_kernel_ms,
+                     "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_PER_S, "traffic": traffic,
+                     "kernel": eng.KernelName(), "kernel_ms_avg": avg_kernel_ms,
                      "mad32_per_jump": MAD32_PER_JUMP, "kernel_jumps_per_s": kernel_jumps_per_s,
                      "hbm_state_GBps": n * STATE_BYTES_PER_KANGAROO / (avg_kernel_ms * 1e-3) / 1e9,
                      "note": "bound is VALU integer multiply issue (SURVEY §8d), not HBM/MFMA; HBM traffic is 0.75 B/jump"},

@@ -116,6 +116,11 @@ int kg_last_kernel_ms(const kg_engine *e, float *ms);
  * workgroups launched.  No counterpart in the reference. */
 int kg_kernel_info(const kg_engine *e, int *k_per_lane, int *delta_words, int *lds_bytes, int *grid);
 
+/* Name of the kernel instantiation a launch will use, as it appears in a rocprofv3 kernel trace
+ * (template arguments: kangaroos per lane, window, delta words, waves per SIMD).  No counterpart in
+ * the reference. */
+int kg_kernel_name(const kg_engine *e, char *buf, size_t buflen);
+
 /* Replaces GPUEngine::AllocatePinnedMemory / FreePinnedMemory (engine.cu:221-233). */
 void *kg_alloc_pinned(size_t size);
 void kg_free_pinned(void *p);

@@ -123,6 +123,9 @@ static const Variant g_variants[] = {
     KG_VARIANT_ROT(12, 4, 3, 1), KG_VARIANT_ROT(12, 4, 8, 1),
     KG_VARIANT_ROT(16, 4, 3, 1), KG_VARIANT_ROT(16, 4, 8, 1),
     KG_VARIANT_ROT(16, 2, 3, 1), KG_VARIANT_ROT(16, 2, 8, 1),
+#ifdef KG_EXTRA_VARIANTS
+    KG_EXTRA_VARIANTS
+#endif
 };
 
 static int env_int(const char *name, int dflt) {
@@ -587,6 +590,18 @@ extern "C" int kg_kick_and_wait(kg_engine *e) {
 extern "C" int kg_last_kernel_ms(const kg_engine *e, float *ms) {
   if (!e || !ms) return fail(KG_ERR_ARG, "kg_last_kernel_ms: bad argument");
   *ms = e->last_ms;
+  return KG_OK;
+}
+
+extern "C" int kg_kernel_name(const kg_engine *e, char *buf, size_t buflen) {
+  if (!e || !buf || buflen == 0) return fail(KG_ERR_ARG, "kg_kernel_name: bad argument");
+  const int dw = e->params_set ? pick_delta_words(e) : e->DW;
+  const Variant *v = find_variant(e->K, dw);
+  if (!v) return fail(KG_ERR_STATE, "kg_kernel_name: no kernel variant for this configuration");
+  if (v->U)
+    snprintf(buf, buflen, "kg_walk_kernel_rot<%d,%d,%d,%d>", v->K, v->U, v->DW, v->W);
+  else
+    snprintf(buf, buflen, "kg_walk_kernel<%d,%d,%d>", v->K, v->DW, v->W);
   return KG_OK;
 }
 

@@ -71,6 +71,7 @@ def load_library():
         "kg_kick_and_wait": ([H], C.c_int),
         "kg_last_kernel_ms": ([H, C.POINTER(C.c_float)], C.c_int),
         "kg_kernel_info": ([H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "kg_kernel_name": ([H, C.c_char_p, C.c_size_t], C.c_int),
         "kg_alloc_pinned": ([C.c_size_t], C.c_void_p),
         "kg_free_pinned": ([C.c_void_p], None),
         "kg_print_device_info": ([], C.c_int),
@@ -89,7 +90,7 @@ ABI_SYMBOLS = [
     "kg_device_count", "kg_default_grid", "kg_create", "kg_destroy", "kg_device_name", "kg_memory_bytes",
     "kg_nb_thread", "kg_group_size", "kg_nb_kangaroo", "kg_set_wild_offset", "kg_set_params", "kg_set_kangaroos",
     "kg_get_kangaroos", "kg_set_kangaroo", "kg_set_nb_run", "kg_kick", "kg_collect", "kg_launch",
-    "kg_kick_and_wait", "kg_last_kernel_ms", "kg_kernel_info", "kg_alloc_pinned", "kg_free_pinned",
+    "kg_kick_and_wait", "kg_last_kernel_ms", "kg_kernel_info", "kg_kernel_name", "kg_alloc_pinned", "kg_free_pinned",
     "kg_print_device_info", "kg_last_error", "kg_version",
 ]
 
@@ -176,6 +177,11 @@ class GPUEngine:
         k, dw, lds, grid = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _chk(self._L.kg_kernel_info(self._h, C.byref(k), C.byref(dw), C.byref(lds), C.byref(grid)))
         return {"k_per_lane": k.value, "delta_words": dw.value, "lds_bytes": lds.value, "grid": grid.value}
+
+    def KernelName(self):
+        buf = C.create_string_buffer(128)
+        _chk(self._L.kg_kernel_name(self._h, buf, C.c_size_t(len(buf))))
+        return buf.value.decode()
 
     def LastKernelMs(self):
         ms = C.c_float(0)
