@@ -131,6 +131,7 @@ class GPUEngine:
         self._cap = max(int(maxFound), min(self.nbKangaroo, 1 << 22))
         self._items = np.zeros(self._cap, dtype=ITEM_DTYPE)
         self.lost = 0
+        self.nb_run = 256  # NB_RUN, constants.h:21
 
     def close(self):
         if self._h:
@@ -198,6 +199,7 @@ class GPUEngine:
 
     def SetNbRun(self, nbRun):
         _chk(self._L.kg_set_nb_run(self._h, nbRun))
+        self.nb_run = int(nbRun)
 
     def SetKangaroos(self, px, py, d):
         n = self.nbKangaroo
