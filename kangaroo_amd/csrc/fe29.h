@@ -1,6 +1,6 @@
 // fe29.h — secp256k1 field arithmetic for gfx950, 9 limbs of 29 bits in 32-bit VGPRs.
 //
-// Why not 4x64 / 8x32 saturated limbs: measured on MI355X (profiles/ubench_r01.txt) a carry
+// Why not 4x64 / 8x32 saturated limbs: measured on MI355X (profiles/ubench_instr_table_r01.txt) a carry
 // instruction (v_add_co/v_addc_co_u32) costs as much issue time as a v_mad_u64_u32 (4.3-5
 // cycles per wave64 against 2.5 for a plain 32-bit op) and every VCC producer->consumer pair
 // needs two wait states.  With 29-bit limbs the 81 partial products of a 256x256 multiply are

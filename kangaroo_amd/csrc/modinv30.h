@@ -37,6 +37,15 @@ KG_HD i64 mad_i64(i32 a, i32 b, i64 c) {
 #endif
 }
 
+// true if the predicate holds in any lane of the wavefront (the host build has one "lane")
+KG_HD bool kg_any_lane(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(p) != 0;
+#else
+  return p;
+#endif
+}
+
 // 30 divsteps on the low words; returns the new zeta and the transition matrix (scaled 2^30)
 KG_HD i32 divsteps_30(i32 zeta, u32 f0, u32 g0, trans2x2 &t) {
   u32 u = 1, v = 0, q = 0, r = 1;
@@ -104,6 +113,52 @@ KG_HD i32 divsteps_30_var(i32 eta, u32 f0, u32 g0, trans2x2 &t) {
   t.v = (i32)v;
   t.q = (i32)q;
   t.r = (i32)r;
+  return eta;
+}
+
+// Branch-free form of the variable-time batch for SIMT: a FIXED number of iterations, each consuming
+// however many of the batch's 30 bits it can (trailing zeros of g, then up to 5 more cleared with one
+// multiple of f), no data-dependent control flow and no v_cndmask (slow on gfx950, measured 22 cycles).
+// Bits a lane has not consumed after NITER iterations are handed to the next batch: scaling all four
+// matrix entries by 2^rem makes the division by 2^30 in update_fg/update_de a division by 2^consumed.
+// Same divstep sequence as divsteps_30_var, only the batch boundaries differ.
+template <int NITER>
+KG_HD i32 divsteps_30_fix(i32 eta, u32 f0, u32 g0, trans2x2 &t) {
+  u32 u = 1, v = 0, q = 0, r = 1;
+  u32 f = f0, g = g0;
+  i32 rem = 30;  // bits left in this batch (0: batch full, the remaining iterations are no-ops)
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    const u32 zeros = (u32)__builtin_ctz(g | (0xFFFFFFFFu << rem));  // sentinel: never more than rem
+    g >>= zeros;
+    u <<= zeros;
+    v <<= zeros;
+    eta -= (i32)zeros;
+    rem -= (i32)zeros;
+    // swap roles when eta < 0 and the batch is not full: (f, g) <- (g, -f); as masks
+    const u32 cm = (u32)(((i32)((u32)eta & ~(u32)(rem - 1))) >> 31);
+    const u32 nf = (g & cm) | (f & ~cm);
+    const u32 ng = (((f & cm) | (g & ~cm)) ^ cm) - cm;
+    const u32 nu = (q & cm) | (u & ~cm);
+    const u32 nq = (((u & cm) | (q & ~cm)) ^ cm) - cm;
+    const u32 nv = (r & cm) | (v & ~cm);
+    const u32 nr = (((v & cm) | (r & ~cm)) ^ cm) - cm;
+    f = nf; g = ng; u = nu; q = nq; v = nv; r = nr;
+    eta = (i32)(((u32)eta ^ cm) - cm);
+    // clear the low min(eta + 1, bits left, 5) bits of g with a multiple of f
+    i32 lim = rem < 5 ? rem : 5;
+    lim = eta + 1 < lim ? eta + 1 : lim;
+    lim = lim < 0 ? 0 : lim;  // eta can only be negative here when the batch is full (rem = 0)
+    const u32 fi = (f * 3u) ^ 2u;  // f^-1 mod 32
+    const u32 w = (0u - g * fi) & ((1u << lim) - 1u);
+    g += f * w;
+    q += u * w;
+    r += v * w;
+  }
+  t.u = (i32)(u << rem);
+  t.v = (i32)(v << rem);
+  t.q = (i32)(q << rem);
+  t.r = (i32)(r << rem);
   return eta;
 }
 
@@ -187,8 +242,12 @@ KG_HD void normalize_30(s30 &r, i32 sign) {
 }
 
 // a: any weak/wide field element.  r: canonical inverse (weak-compatible), 0 if a == 0 mod p.
-// VAR = false: fixed 20 x 30 divsteps (no divergence).  VAR = true: variable-time batches until g == 0.
-template <bool VAR>
+// MODE 0: fixed 20 x 30 divsteps (constant time).  MODE 1: variable-time batches with a per-lane loop.
+// MODE 2: variable-time batches of KG_INV_NITER branch-free iterations (the SIMT form; default).
+#ifndef KG_INV_NITER
+#define KG_INV_NITER 8
+#endif
+template <int MODE, int NITER = KG_INV_NITER>
 KG_HD void fe_inv_t(fe &r, const fe &a_in) {
   fe a = a_in;
   fe_canon(a);
@@ -205,7 +264,21 @@ KG_HD void fe_inv_t(fe &r, const fe &a_in) {
   for (int i = 0; i < 8; ++i) g.v[i] = (i32)(((a.l[i] >> i) | (a.l[i + 1] << (29 - i))) & (u32)M30);
   g.v[8] = (i32)(a.l[8] >> 8);
   i32 zeta = -1;
-  if (VAR) {
+  if (MODE == 2) {
+    u32 nz = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nz |= (u32)g.v[i];
+#pragma unroll 1
+    while (kg_any_lane(nz != 0)) {  // lanes that are done keep iterating harmlessly (g = 0 leaves d, f alone)
+      trans2x2 t;
+      zeta = divsteps_30_fix<NITER>(zeta, (u32)f.v[0], (u32)g.v[0], t);
+      update_de_30(d, e, t);
+      update_fg_30(f, g, t);
+      nz = 0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) nz |= (u32)g.v[i];
+    }
+  } else if (MODE == 1) {
     // delta = 1 variant: at most 724 divsteps (25 batches) in theory, 17-19 batches in practice
     u32 nz = 0;
 #pragma unroll
@@ -238,8 +311,8 @@ KG_HD void fe_inv_t(fe &r, const fe &a_in) {
 }
 
 #ifndef KG_INV_VARTIME
-#define KG_INV_VARTIME 1
+#define KG_INV_VARTIME 2
 #endif
-KG_HD void fe_inv(fe &r, const fe &a) { fe_inv_t<KG_INV_VARTIME != 0>(r, a); }
+KG_HD void fe_inv(fe &r, const fe &a) { fe_inv_t<KG_INV_VARTIME>(r, a); }
 
 }  // namespace kg

@@ -25,8 +25,9 @@ void fh_submul(u32 r[8], const u32 a[8], const u32 b[8], const u32 c[8]) {
   fe_sub_wide(d, x, y); fe_mul(z, d, w); fe_canon(z); fe_to_words(r, z);
 }
 void fh_canon(u32 r[8], const u32 a[8]) { fe x; fe_from_words(x, a); fe_canon(x); fe_to_words(r, x); }
-void fh_inv(u32 r[8], const u32 a[8]) { fe x, z; fe_from_words(x, a); fe_inv_t<false>(z, x); fe_canon(z); fe_to_words(r, z); }
-void fh_inv_var(u32 r[8], const u32 a[8]) { fe x, z; fe_from_words(x, a); fe_inv_t<true>(z, x); fe_canon(z); fe_to_words(r, z); }
+void fh_inv(u32 r[8], const u32 a[8]) { fe x, z; fe_from_words(x, a); fe_inv_t<0>(z, x); fe_canon(z); fe_to_words(r, z); }
+void fh_inv_var(u32 r[8], const u32 a[8]) { fe x, z; fe_from_words(x, a); fe_inv_t<1>(z, x); fe_canon(z); fe_to_words(r, z); }
+void fh_inv_fix(u32 r[8], const u32 a[8]) { fe x, z; fe_from_words(x, a); fe_inv_t<2>(z, x); fe_canon(z); fe_to_words(r, z); }
 // one affine jump exactly as the kernel's back pass does it, given dx^-1
 void fh_jump(u32 rx[8], u32 ry[8], const u32 x[8], const u32 y[8], const u32 jx[8], const u32 jy[8]) {
   fe X, Y, JX, JY, dx, dxi, dy, s, p2, RX, t, RY;

@@ -48,6 +48,7 @@ def test_edge_cube(L):
         assert call(L.fh_sqr, a) == a * a % P
         assert call(L.fh_inv, a) == (pow(a % P, -1, P) if a % P else 0)
         assert call(L.fh_inv_var, a) == (pow(a % P, -1, P) if a % P else 0)
+        assert call(L.fh_inv_fix, a) == (pow(a % P, -1, P) if a % P else 0)
         for b in EDGE:
             assert call(L.fh_mul, a, b) == a * b % P, (hex(a), hex(b))
             assert call(L.fh_sub, a, b) == (a - b) % P
@@ -71,6 +72,7 @@ def test_random(L):
     for _ in range(3000):
         a = rnd.getrandbits(rnd.choice([256, 256, 200, 64, 9]))
         assert call(L.fh_inv_var, a) == (pow(a % P, -1, P) if a % P else 0)
+        assert call(L.fh_inv_fix, a) == (pow(a % P, -1, P) if a % P else 0)
     # sparse / low-weight / high-weight patterns stress carry paths
     for _ in range(2000):
         bits = rnd.sample(range(256), rnd.randint(1, 6))
@@ -82,6 +84,8 @@ def test_random(L):
         assert call(L.fh_inv, b) == (pow(b % P, -1, P) if b % P else 0)
         assert call(L.fh_inv_var, b) == (pow(b % P, -1, P) if b % P else 0)
         assert call(L.fh_inv_var, a) == pow(a, -1, P)
+        assert call(L.fh_inv_fix, b) == (pow(b % P, -1, P) if b % P else 0)
+        assert call(L.fh_inv_fix, a) == pow(a, -1, P)
 
 
 def test_matches_oracle_and_golden(L, golden):
