@@ -22,6 +22,7 @@
 #include "../../include/kangaroo_amd.h"
 #include "walk_kernel.h"
 #include "walk_kernel_rot.h"
+#include "walk_kernel_stream.h"
 
 using namespace kg;
 
@@ -84,6 +85,9 @@ struct kg_engine {
   u64 n = 0, cap = 0;
   u32 threads = 0, grid = 0;
   int K = 0, DW = 0;
+  bool streaming = false;     // streaming kernel (walk_kernel_stream.h) instead of the register-resident one
+  u32 *ws = nullptr;          // its workspace
+  size_t ws_bytes = 0;
   u32 nb_run = KG_NB_RUN;
   u32 max_found = 0;
   hipStream_t stream = nullptr;
@@ -128,6 +132,17 @@ static const Variant g_variants[] = {
 #endif
 };
 
+typedef void (*stream_fn)(StreamArgs);
+struct StreamVariant {
+  int DW, W;
+  stream_fn fn;
+};
+static const StreamVariant g_stream_variants[] = {
+    {3, 2, kg_walk_kernel_stream<3, 2>}, {8, 2, kg_walk_kernel_stream<8, 2>},
+    {3, 3, kg_walk_kernel_stream<3, 3>}, {8, 3, kg_walk_kernel_stream<8, 3>},
+    {3, 1, kg_walk_kernel_stream<3, 1>}, {8, 1, kg_walk_kernel_stream<8, 1>},
+};
+
 static int env_int(const char *name, int dflt) {
   const char *s = getenv(name);
   return (s && *s) ? atoi(s) : dflt;
@@ -138,6 +153,18 @@ static const Variant *find_variant(int K, int DW) {
   for (const Variant &v : g_variants)
     if (v.K == K && v.DW == DW && (w == 0 || v.W == w) && (u < 0 || v.U == u)) return &v;
   return nullptr;
+}
+
+static const StreamVariant *find_stream_variant(int DW) {
+  const int w = env_int("KG_W", 2);
+  for (const StreamVariant &v : g_stream_variants)
+    if (v.DW == DW && v.W == w) return &v;
+  return nullptr;
+}
+
+static bool stream_mode() {
+  const char *m = getenv("KG_MODE");
+  return m && strcmp(m, "stream") == 0;
 }
 
 static int default_k() {
@@ -239,6 +266,7 @@ extern "C" int kg_destroy(kg_engine *e) {
   if (e->count_dev) (void)hipFree(e->count_dev);
   if (e->count_host) (void)hipHostFree(e->count_host);
   if (e->stage) (void)hipHostFree(e->stage);
+  if (e->ws) (void)hipFree(e->ws);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return KG_OK;
@@ -266,7 +294,15 @@ extern "C" int kg_create(int gpu_id, int groups, int per_group, uint32_t max_fou
   e->per_group = per_group;
   e->cus = prop.multiProcessorCount;
   e->n = (u64)KG_GROUP_SIZE * (u64)groups * (u64)per_group;
-  e->K = default_k();
+  e->streaming = stream_mode();
+  if (e->streaming) {
+    // K kangaroos per lane such that the herd fills about KG_W (2) waves per SIMD; KG_K overrides
+    const u64 lanes = (u64)e->cus * 4 * 64 * (u64)env_int("KG_W", 2);
+    u64 k = env_int("KG_K", 0) > 0 ? (u64)env_int("KG_K", 0) : (e->n + lanes - 1) / lanes;
+    e->K = (int)std::min<u64>(std::max<u64>(k, env_int("KG_K", 0) > 0 ? 1 : 4), 1024);
+  } else {
+    e->K = default_k();
+  }
   e->DW = 3;
   const u64 per_lane = (e->n + e->K - 1) / e->K;
   const u64 blocks = (per_lane + WALK_BLOCK - 1) / WALK_BLOCK;
@@ -480,8 +516,20 @@ extern "C" int kg_kick(kg_engine *e) {
   if (e->pending >= 0) return fail(KG_ERR_STATE, "GPUEngine: Kernel: previous launch not collected");
   if (bind(e) != KG_OK) return KG_ERR_HIP;
   e->DW = pick_delta_words(e);
-  const Variant *v = find_variant(e->K, e->DW);
-  if (!v) return fail(KG_ERR_STATE, "GPUEngine: Kernel: no kernel variant for this configuration");
+  const Variant *v = e->streaming ? nullptr : find_variant(e->K, e->DW);
+  const StreamVariant *sv = e->streaming ? find_stream_variant(e->DW) : nullptr;
+  if (!v && !sv) return fail(KG_ERR_STATE, "GPUEngine: Kernel: no kernel variant for this configuration");
+  if (sv) {
+    const size_t need = (size_t)(27 + e->DW) * (size_t)e->K * (size_t)e->threads * sizeof(u32);
+    if (need > e->ws_bytes) {
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (e->ws) (void)hipFree(e->ws);
+      e->ws = nullptr;
+      e->ws_bytes = 0;
+      HIPCHK(hipMalloc((void **)&e->ws, need));
+      e->ws_bytes = need;
+    }
+  }
   const int b = e->next_buf;
   WalkArgs a;
   a.X = e->X;
@@ -497,12 +545,20 @@ extern "C" int kg_kick(kg_engine *e) {
   a.out = e->out_dev[b];
   a.out_count = e->count_dev + b;
   a.max_found = e->max_found;
-  const size_t lds = v->U ? walk_rot_lds_bytes(e->K, e->DW) : walk_lds_bytes(e->K, e->DW);
+  const size_t lds = sv ? walk_stream_lds_bytes(e->DW) : v->U ? walk_rot_lds_bytes(e->K, e->DW) : walk_lds_bytes(e->K, e->DW);
   if (lds > 64 * 1024)  // above the default dynamic-LDS limit (gfx950 has 160 KiB per CU)
     HIPCHK(hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipMemsetAsync(e->count_dev + b, 0, sizeof(u32), e->stream));
   HIPCHK(hipEventRecord(e->ev_start[b], e->stream));
-  hipLaunchKernelGGL(v->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, a);
+  if (sv) {
+    StreamArgs sa;
+    sa.a = a;
+    sa.ws = e->ws;
+    sa.K = (u32)e->K;
+    hipLaunchKernelGGL(sv->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, sa);
+  } else {
+    hipLaunchKernelGGL(v->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, a);
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev_stop[b], e->stream));
   HIPCHK(hipMemcpyAsync(e->count_host + b, e->count_dev + b, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
@@ -596,6 +652,12 @@ extern "C" int kg_last_kernel_ms(const kg_engine *e, float *ms) {
 extern "C" int kg_kernel_name(const kg_engine *e, char *buf, size_t buflen) {
   if (!e || !buf || buflen == 0) return fail(KG_ERR_ARG, "kg_kernel_name: bad argument");
   const int dw = e->params_set ? pick_delta_words(e) : e->DW;
+  if (e->streaming) {
+    const StreamVariant *sv = find_stream_variant(dw);
+    if (!sv) return fail(KG_ERR_STATE, "kg_kernel_name: no kernel variant for this configuration");
+    snprintf(buf, buflen, "kg_walk_kernel_stream<%d,%d>", sv->DW, sv->W);
+    return KG_OK;
+  }
   const Variant *v = find_variant(e->K, dw);
   if (!v) return fail(KG_ERR_STATE, "kg_kernel_name: no kernel variant for this configuration");
   if (v->U)
@@ -611,7 +673,8 @@ extern "C" int kg_kernel_info(const kg_engine *e, int *k_per_lane, int *delta_wo
   if (k_per_lane) *k_per_lane = e->K;
   if (delta_words) *delta_words = dw;
   const Variant *v = find_variant(e->K, dw);
-  if (lds_bytes) *lds_bytes = (int)((v && v->U) ? walk_rot_lds_bytes(e->K, dw) : walk_lds_bytes(e->K, dw));
+  if (lds_bytes)
+    *lds_bytes = (int)(e->streaming ? walk_stream_lds_bytes(dw) : (v && v->U) ? walk_rot_lds_bytes(e->K, dw) : walk_lds_bytes(e->K, dw));
   if (grid) *grid = (int)e->grid;
   return KG_OK;
 }

@@ -9,7 +9,7 @@
 //
 // Values: v = sum l[i] * 2^(29 i).  Three states are used:
 //   canonical : v in [0,p), l[0..7] < 2^29, l[8] < 2^24
-//   weak      : l[0] < 2^29 + 2^18, l[1] < 2^29 + 2^11, l[2..7] < 2^29 (+1), l[8] <= 2^24;  v < 2^256 + 2^50
+//   weak      : l[0] < 2^29 + 2^18, l[1] < 2^29 + 2^11, l[2] < 2^29 + 2^16, l[3..7] < 2^29 (+1), l[8] <= 2^24;  v < 2^256 + 2^62
 //   wide      : l[i] < 2^32 (a limb-wise a + c*p - b that has not been carried);   v < 2^259
 // fe_mul takes (wide, weak) and returns weak; fe_sqr takes weak and returns weak.
 //
@@ -145,30 +145,50 @@ KG_HD void fe_canon(fe &r) {
 }
 
 // ---- multiplication: a wide (limbs < 2^31.1, value < 2^259), b weak -> weak ----------------
+// acc + a * b, one v_mad_u64_u32.  Written as an asm statement on the device so that the column sums below
+// stay single accumulate chains that start from the carry of the previous column: left as C, the
+// compiler reassociates the 64-bit sums (chains started from zero, carries and the 2^37 term added with
+// separate 64-bit adds and shifts), about 30 % more instructions per multiplication.
+KG_HD u64 mad_u64(u32 a, u32 b, u64 acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry) : "v"(a), "v"(b));
+  return acc;
+#else
+  return acc + (u64)a * b;
+#endif
+}
+// the same with a small constant (kept in an SGPR by the compiler)
+KG_HD u64 mad_u64_k(u32 a, u32 k, u64 acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry) : "v"(a), "s"(k));
+  return acc;
+#else
+  return acc + (u64)a * k;
+#endif
+}
+
 KG_HD void fe_reduce_cols(fe &r, u32 (&t)[9], u64 t9acc) {
   // t: columns 0..8 carried to 29 bits with the fold of the high half applied;
   // t9acc (< 2^36, because wide limbs push up to 2^34 of carry out of column 8): weight 2^261.
   // 2^261 = R0 + R1 * 2^29 (mod p) and 2^256 = 977 + 8 * 2^29 (mod p).
-  u32 t9lo = (u32)t9acc & M29;
-  u32 t9hi = (u32)(t9acc >> 29);  // weight 2^290 = (R0 + R1 * 2^29) * 2^29
-  u32 v8 = t[8] >> 24;
-  t[8] &= 0xFFFFFFu;
-  u64 c = (u64)t[0] + (u64)(v8 * 977u) + (u64)t9lo * FE_R0;
+  // Only limbs 0 and 1 are carried; what is left (< 2^16) is parked in limb 2, which the weak
+  // form allows, so there is no carry chain through limbs 3..8.
+  const u32 t9lo = (u32)t9acc & M29;
+  const u32 t9hi = (u32)(t9acc >> 29);  // weight 2^290 = (R0 + R1 * 2^29) * 2^29
+  const u32 v8 = t[8] >> 24;
+  u64 c = (u64)(t[0] + v8 * 977u);      // < 2^29 + 2^15
+  c = mad_u64_k(t9lo, FE_R0, c);
   r.l[0] = (u32)c & M29;
   c >>= 29;
-  c += (u64)t[1] + (u64)(v8 << 3) + (u64)t9lo * FE_R1 + (u64)(t9hi * FE_R0);
+  c += (u64)(t[1] + (v8 << 3) + t9hi * FE_R0);  // < 2^29 + 2^8 + 2^22
+  c = mad_u64_k(t9lo, FE_R1, c);
   r.l[1] = (u32)c & M29;
-  c >>= 29;
-  u32 cc = (u32)c + t[2] + (t9hi << 8);  // c < 2^11, t9hi < 2^7
-  r.l[2] = cc & M29;
-  cc >>= 29;
+  r.l[2] = t[2] + (u32)(c >> 29) + (t9hi << 8);  // < 2^29 + 2^9 + 2^15
 #pragma unroll
-  for (int i = 3; i < 8; ++i) {
-    cc += t[i];
-    r.l[i] = cc & M29;
-    cc >>= 29;
-  }
-  r.l[8] = t[8] + cc;
+  for (int i = 3; i < 8; ++i) r.l[i] = t[i];
+  r.l[8] = t[8] & 0xFFFFFFu;
 }
 
 KG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
@@ -178,7 +198,7 @@ KG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
 #pragma unroll
   for (int k = 9; k <= 16; ++k) {
 #pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc += (u64)a.l[i] * b.l[k - i];
+    for (int i = k - 8; i <= 8; ++i) acc = mad_u64(a.l[i], b.l[k - i], acc);
     h[k - 9] = (u32)acc & M29;
     acc >>= 29;
   }
@@ -188,13 +208,13 @@ KG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
 #pragma unroll
   for (int k = 0; k <= 8; ++k) {
 #pragma unroll
-    for (int i = 0; i <= k; ++i) acc += (u64)a.l[i] * b.l[k - i];
-    acc += (u64)h[k] * FE_R0;
-    if (k > 0) acc += (u64)h[k - 1] * FE_R1;
+    for (int i = 0; i <= k; ++i) acc = mad_u64(a.l[i], b.l[k - i], acc);
+    acc = mad_u64_k(h[k], FE_R0, acc);
+    if (k > 0) acc = mad_u64_k(h[k - 1], FE_R1, acc);
     t[k] = (u32)acc & M29;
     acc >>= 29;
   }
-  acc += (u64)h[8] * FE_R1;
+  acc = mad_u64_k(h[8], FE_R1, acc);
   fe_reduce_cols(r, t, acc);
 }
 
@@ -207,8 +227,8 @@ KG_HD void fe_sqr(fe &r, const fe &a) {
 #pragma unroll
   for (int k = 9; k <= 16; ++k) {
 #pragma unroll
-    for (int i = k - 8; 2 * i < k; ++i) acc += (u64)d[i] * a.l[k - i];
-    if ((k & 1) == 0) acc += (u64)a.l[k / 2] * a.l[k / 2];
+    for (int i = k - 8; 2 * i < k; ++i) acc = mad_u64(d[i], a.l[k - i], acc);
+    if ((k & 1) == 0) acc = mad_u64(a.l[k / 2], a.l[k / 2], acc);
     h[k - 9] = (u32)acc & M29;
     acc >>= 29;
   }
@@ -217,14 +237,14 @@ KG_HD void fe_sqr(fe &r, const fe &a) {
 #pragma unroll
   for (int k = 0; k <= 8; ++k) {
 #pragma unroll
-    for (int i = 0; 2 * i < k; ++i) acc += (u64)d[i] * a.l[k - i];
-    if ((k & 1) == 0) acc += (u64)a.l[k / 2] * a.l[k / 2];
-    acc += (u64)h[k] * FE_R0;
-    if (k > 0) acc += (u64)h[k - 1] * FE_R1;
+    for (int i = 0; 2 * i < k; ++i) acc = mad_u64(d[i], a.l[k - i], acc);
+    if ((k & 1) == 0) acc = mad_u64(a.l[k / 2], a.l[k / 2], acc);
+    acc = mad_u64_k(h[k], FE_R0, acc);
+    if (k > 0) acc = mad_u64_k(h[k - 1], FE_R1, acc);
     t[k] = (u32)acc & M29;
     acc >>= 29;
   }
-  acc += (u64)h[8] * FE_R1;
+  acc = mad_u64_k(h[8], FE_R1, acc);
   fe_reduce_cols(r, t, acc);
 }
 

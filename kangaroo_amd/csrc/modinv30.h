@@ -29,9 +29,11 @@ KG_HD i32 p30(int i) { return i == 0 ? -0x3D1 : i == 1 ? -4 : i == 8 ? 65536 : 0
 // sign corrections (3 instructions per product); the hardware has the signed form.
 KG_HD i64 mad_i64(i32 a, i32 b, i64 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  i64 r;
-  asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
-  return r;
+  // accumulate in place; the carry-out goes to a scratch SGPR pair so that neighbouring products do
+  // not serialise on VCC
+  u64 carry;
+  asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(c), "=s"(carry) : "v"(a), "v"(b));
+  return c;
 #else
   return c + (i64)a * b;
 #endif
@@ -217,6 +219,74 @@ KG_HD void update_de_30(s30 &d, s30 &e, const trans2x2 &t) {
   e.v[8] = (i32)ce;
 }
 
+// Same product, but the instruction keeps its place in the source order (volatile): used by the fused
+// update below to interleave four independent carry chains by hand — left to itself the scheduler
+// emits each chain back to back and a lone wave per SIMD then waits out every result latency.
+KG_HD i64 mad_i64_ord(i32 a, i32 b, i64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 carry;
+  asm volatile("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(c), "=s"(carry) : "v"(a), "v"(b));
+  return c;
+#else
+  return c + (i64)a * b;
+#endif
+}
+
+// update_de_30 and update_fg_30 in one pass over the limbs, the four chains (d, e, f, g) round-robin
+KG_HD void update_defg_30(s30 &d, s30 &e, s30 &f, s30 &g, const trans2x2 &t) {
+  const i32 u = t.u, v = t.v, q = t.q, r = t.r;
+  const i32 sd = d.v[8] >> 31, se = e.v[8] >> 31;
+  i32 md = (u & sd) + (v & se);
+  i32 me = (q & sd) + (r & se);
+  i64 cd = mad_i64_ord(u, d.v[0], 0);
+  i64 ce = mad_i64_ord(q, d.v[0], 0);
+  i64 cf = mad_i64_ord(u, f.v[0], 0);
+  i64 cg = mad_i64_ord(q, f.v[0], 0);
+  cd = mad_i64_ord(v, e.v[0], cd);
+  ce = mad_i64_ord(r, e.v[0], ce);
+  cf = mad_i64_ord(v, g.v[0], cf);
+  cg = mad_i64_ord(r, g.v[0], cg);
+  md -= (i32)((P_INV30 * (u32)cd + (u32)md) & (u32)M30);
+  me -= (i32)((P_INV30 * (u32)ce + (u32)me) & (u32)M30);
+  cf >>= 30;
+  cg >>= 30;
+  cd = mad_i64_ord(p30(0), md, cd);
+  ce = mad_i64_ord(p30(0), me, ce);
+  cd >>= 30;
+  ce >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; ++i) {
+    cd = mad_i64_ord(u, d.v[i], cd);
+    ce = mad_i64_ord(q, d.v[i], ce);
+    cf = mad_i64_ord(u, f.v[i], cf);
+    cg = mad_i64_ord(q, f.v[i], cg);
+    cd = mad_i64_ord(v, e.v[i], cd);
+    ce = mad_i64_ord(r, e.v[i], ce);
+    cf = mad_i64_ord(v, g.v[i], cf);
+    cg = mad_i64_ord(r, g.v[i], cg);
+    if (i == 1) {  // p30(1) = -4
+      cd -= (i64)md << 2;
+      ce -= (i64)me << 2;
+    }
+    if (i == 8) {  // p30(8) = 2^16
+      cd += (i64)md << 16;
+      ce += (i64)me << 16;
+    }
+    d.v[i - 1] = (i32)cd & M30;
+    e.v[i - 1] = (i32)ce & M30;
+    f.v[i - 1] = (i32)cf & M30;
+    g.v[i - 1] = (i32)cg & M30;
+    cd >>= 30;
+    ce >>= 30;
+    cf >>= 30;
+    cg >>= 30;
+  }
+  d.v[8] = (i32)cd;
+  e.v[8] = (i32)ce;
+  f.v[8] = (i32)cf;
+  g.v[8] = (i32)cg;
+}
+
 // bring d from (-2p, p) into [0, p), negating first when sign < 0
 KG_HD void normalize_30(s30 &r, i32 sign) {
   i32 cond_add = r.v[8] >> 31;
@@ -272,8 +342,7 @@ KG_HD void fe_inv_t(fe &r, const fe &a_in) {
     while (kg_any_lane(nz != 0)) {  // lanes that are done keep iterating harmlessly (g = 0 leaves d, f alone)
       trans2x2 t;
       zeta = divsteps_30_fix<NITER>(zeta, (u32)f.v[0], (u32)g.v[0], t);
-      update_de_30(d, e, t);
-      update_fg_30(f, g, t);
+      update_defg_30(d, e, f, g, t);
       nz = 0;
 #pragma unroll
       for (int i = 0; i < 9; ++i) nz |= (u32)g.v[i];

@@ -1,0 +1,265 @@
+// walk_kernel_stream.h — streaming form of the jump kernel: the herd lives in HBM during the launch and
+// only the kangaroo being jumped (plus the prefetched next one) is in registers.
+//
+// Why: with the herd in registers (walk_kernel_rot.h) a lane can hold 16 kangaroos, the kernel runs one
+// wave per SIMD, and the per-lane modular inverse is amortised over 16 jumps only (30 % of the cycles).
+// Measured on MI355X (tools/ubench_body.hip) the arithmetic of one jump issues 28 % faster with two or
+// more waves per SIMD than with one.  Here a lane owns K kangaroos with K set at run time (64 for the
+// bench herd), the inverse is amortised over K, registers hold one body's working set, so 2-3 waves per
+// SIMD fit, and the code is one rolled body (~12 KB, instruction-cache resident).  The price is HBM
+// traffic: 4 * (2 * (18 + DW) + 2 * 9) bytes per jump (240 B for DW = 3), all of it lane-contiguous
+// dword rows.
+//
+// Workspace (engine-private, HBM): rows of `threads` u32; kangaroo slot k of lane T uses rows
+//   k * R + 0..8   x limbs        k * R + 9..17        y limbs
+//   k * R + 18..   DW delta words k * R + 18 + DW ..   9 limbs of the stored partial product P[k]
+// with R = 27 + DW.  The prologue converts X/Y planes into the workspace, the epilogue converts back and
+// adds the deltas to D, so the engine's resident format (walk_kernel.h) is unchanged.
+//
+// The step itself is the fused pass of walk_kernel_rot.h: same arithmetic, same results.
+#pragma once
+#include "walk_kernel_rot.h"
+
+namespace kg {
+
+struct StreamArgs {
+  WalkArgs a;
+  u32 *ws;  // workspace, R * K rows of a.threads u32
+  u32 K;    // kangaroos per lane
+};
+
+template <int DW>
+struct StreamRec {
+  fe x, y;
+  dlt<DW> dl;
+};
+
+// row r of the workspace for this lane: uniform base (SGPR) + per-lane byte offset (VGPR)
+__device__ __forceinline__ const u32 *ws_row(const u32 *ws, u32 threads, u32 row) {
+  return ws + (u64)row * threads;
+}
+__device__ __forceinline__ u32 ld_lane(const u32 *row, u32 off_bytes) {
+  return *(const u32 *)((const char *)row + off_bytes);
+}
+__device__ __forceinline__ void st_lane(u32 *row, u32 off_bytes, u32 v) { *(u32 *)((char *)row + off_bytes) = v; }
+
+template <int DW, int W>
+__global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArgs sa) {
+  const WalkArgs &a = sa.a;
+  constexpr u32 R = 27 + DW;
+  extern __shared__ u32 lds[];
+  u32 *jt = lds;                           // [64][JT_STRIDE]
+  u32 *jdist = lds + NB_JUMP * JT_STRIDE;  // [64][DW]
+
+  const u32 tid = threadIdx.x;
+  for (u32 i = tid; i < NB_JUMP * 18; i += WALK_BLOCK) {
+    u32 row = i / 18, col = i % 18;
+    jt[row * JT_STRIDE + col] = a.jt->pxy[row][col];
+  }
+  for (u32 i = tid; i < NB_JUMP * DW; i += WALK_BLOCK) jdist[i] = a.jt->dist[i / DW][i % DW];
+  __syncthreads();
+
+  const u32 Tl = blockIdx.x * WALK_BLOCK + tid;  // lane index < threads
+  const u32 off = Tl * 4u;                       // byte offset inside a workspace row
+  const u64 T = Tl;
+  const u32 K = sa.K;
+  const u32 threads = a.threads;
+  u32 *ws = sa.ws;
+
+  auto load_rec = [&](StreamRec<DW> &r, u32 id) {
+    const u32 base = id * R;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.x.l[i] = ld_lane(ws_row(ws, threads, base + i), off);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.y.l[i] = ld_lane(ws_row(ws, threads, base + 9 + i), off);
+#pragma unroll
+    for (int i = 0; i < DW; ++i) r.dl.w[i] = ld_lane(ws_row(ws, threads, base + 18 + i), off);
+  };
+  auto load_p = [&](fe &q, u32 id) {
+    const u32 base = id * R + 18 + DW;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) q.l[i] = ld_lane(ws_row(ws, threads, base + i), off);
+  };
+
+  // ---- prologue: X/Y planes -> workspace, zero deltas, prefix products of the first step's dx (ascending) ----
+  fe acc;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc.l[i] = (i == 0);
+#pragma unroll 1
+  for (u32 k = 0; k < K; ++k) {
+    const u64 p = T + (u64)k * threads;
+    u32 w[8];
+    fe x, y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u64 v = a.X[(u64)i * a.cap + p];
+      w[2 * i] = (u32)v;
+      w[2 * i + 1] = (u32)(v >> 32);
+    }
+    fe_from_words(x, w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u64 v = a.Y[(u64)i * a.cap + p];
+      w[2 * i] = (u32)v;
+      w[2 * i + 1] = (u32)(v >> 32);
+    }
+    fe_from_words(y, w);
+    const u32 *row = jt + (x.l[0] & (NB_JUMP - 1)) * JT_STRIDE;
+    fe jx, dx;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) jx.l[i] = row[i];
+    fe_sub_wide(dx, x, jx);
+    fe_mul(acc, dx, acc);
+    const u32 base = k * R;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + i), off, x.l[i]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + 9 + i), off, y.l[i]);
+#pragma unroll
+    for (int i = 0; i < DW; ++i) st_lane((u32 *)ws_row(ws, threads, base + 18 + i), off, 0u);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + 18 + DW + i), off, acc.l[i]);
+  }
+
+  // ---- steps: pass `run` visits the ids descending when run is even (the prologue went up), ascending when odd ----
+  u32 run = 0;
+#pragma unroll 1
+  do {
+    const bool asc = (run & 1) != 0;
+    const int dir = asc ? 1 : -1;
+    // operands of the first kangaroo of the pass: requested before the inversion, which hides the latency
+    StreamRec<DW> cur;
+    fe cur_q;
+    {
+      const u32 id0 = asc ? 0u : K - 1;
+      load_rec(cur, id0);
+      const u32 nb0 = K > 1 ? (u32)((int)id0 + dir) : id0;
+      load_p(cur_q, nb0);
+    }
+    fe u;
+    fe_inv(u, acc);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc.l[i] = (i == 0);
+
+#pragma unroll 1
+    for (u32 t = 0; t < K; ++t) {
+      const u32 id = asc ? t : K - 1 - t;
+      // prefetch the next kangaroo (clamped at the end of the pass: loads a valid slot that is not used)
+      StreamRec<DW> nxt;
+      fe nxt_q;
+      {
+        const u32 tn = t + 1 < K ? t + 1 : t;
+        const u32 idn = asc ? tn : K - 1 - tn;
+        int nbn = (int)idn + dir;
+        nbn = nbn < 0 ? 0 : (nbn > (int)K - 1 ? (int)K - 1 : nbn);
+        load_rec(nxt, idn);
+        load_p(nxt_q, (u32)nbn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      const u32 jmp = cur.x.l[0] & (NB_JUMP - 1);
+      const u32 *row = jt + jmp * JT_STRIDE;
+      fe jx, jy;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        jx.l[i] = row[i];
+        jy.l[i] = row[9 + i];
+      }
+      fe dx, dxi;
+      // dx_id^-1 = u * (product of the ids still to come in this pass)
+      if (t + 1 < K) {
+        fe_mul(dxi, cur_q, u);
+        fe_sub_wide(dx, cur.x, jx);
+        fe_mul(u, dx, u);
+      } else {
+        dxi = u;
+      }
+      fe dy, s, p2, rx, tt, ry;
+      fe_sub_wide(dy, cur.y, jy);
+      fe_mul(s, dy, dxi);
+      fe_sqr(p2, s);
+      fe_sub2_wide(rx, p2, jx, cur.x);
+      fe_canon(rx);
+      fe_sub_wide(tt, cur.x, rx);
+      fe_mul(ry, tt, s);
+      fe_sub_wide(ry, ry, cur.y);
+      fe_weak(ry);
+      delta_add<DW>(cur.dl.w, jdist + jmp * DW);
+
+      // next step's dx and running product
+      {
+        const u32 *row2 = jt + (rx.l[0] & (NB_JUMP - 1)) * JT_STRIDE;
+        fe jx2, dx2;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) jx2.l[i] = row2[i];
+        fe_sub_wide(dx2, rx, jx2);
+        fe_mul(acc, dx2, acc);
+      }
+      {
+        const u32 base = id * R;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + i), off, rx.l[i]);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + 9 + i), off, ry.l[i]);
+#pragma unroll
+        for (int i = 0; i < DW; ++i) st_lane((u32 *)ws_row(ws, threads, base + 18 + i), off, cur.dl.w[i]);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + 18 + DW + i), off, acc.l[i]);
+      }
+
+      // distinguished point: (x.bits64[3] & dpMask) == 0   (math/gpu/compute.h:54)
+      const u32 top_hi = (rx.l[8] << 8) | (rx.l[7] >> 21);
+      const u32 top_lo = (rx.l[7] << 11) | (rx.l[6] >> 18);
+      const u64 p = T + (u64)id * threads;
+      const bool is_dp = ((top_hi & a.dp_mask_hi) | (top_lo & a.dp_mask_lo)) == 0 && p < a.n;
+      const unsigned long long m = __ballot(is_dp);
+      if (m != 0) {
+        const u32 lane = __lane_id();
+        const u32 leader = (u32)__ffsll(m) - 1;
+        u32 basep = 0;
+        if (lane == leader) basep = atomicAdd(a.out_count, (u32)__popcll(m));
+        basep = __shfl(basep, (int)leader);
+        if (is_dp) {
+          const u32 pos = basep + (u32)__popcll(m & ((1ull << lane) - 1ull));
+          if (pos < a.max_found) {
+            DpItemDev *it = a.out + pos;
+            u32 w[8];
+            fe_to_words(w, rx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) it->x[i] = w[i];
+            add_dist_256<DW>(w, a.D, a.cap, p, cur.dl);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) it->d[i] = w[i];
+            it->kidx = p;
+          }
+        }
+      }
+      cur = nxt;
+      cur_q = nxt_q;
+    }
+  } while (++run < a.nb_run);
+
+  // ---- epilogue: workspace -> X/Y planes (canonical), D += delta ----
+#pragma unroll 1
+  for (u32 k = 0; k < K; ++k) {
+    StreamRec<DW> r;
+    load_rec(r, k);
+    const u64 p = T + (u64)k * threads;
+    u32 w[8];
+    fe_canon(r.x);
+    fe_to_words(w, r.x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.X[(u64)i * a.cap + p] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
+    fe_canon(r.y);
+    fe_to_words(w, r.y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.Y[(u64)i * a.cap + p] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
+    add_dist_256<DW>(w, a.D, a.cap, p, r.dl);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.D[(u64)i * a.cap + p] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
+  }
+}
+
+constexpr size_t walk_stream_lds_bytes(int DW) { return (size_t)(NB_JUMP * JT_STRIDE + NB_JUMP * DW) * sizeof(u32); }
+
+}  // namespace kg
