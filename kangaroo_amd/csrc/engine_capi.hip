@@ -163,8 +163,10 @@ static const StreamVariant *find_stream_variant(int DW) {
 }
 
 static bool stream_mode() {
+  // default: the streaming kernel (measured faster, profiles/r01_variants.txt); KG_MODE=reg selects the
+  // register-resident kernels
   const char *m = getenv("KG_MODE");
-  return m && strcmp(m, "stream") == 0;
+  return !(m && strcmp(m, "reg") == 0);
 }
 
 static int default_k() {

@@ -34,14 +34,20 @@ struct StreamRec {
   dlt<DW> dl;
 };
 
-// row r of the workspace for this lane: uniform base (SGPR) + per-lane byte offset (VGPR)
-__device__ __forceinline__ const u32 *ws_row(const u32 *ws, u32 threads, u32 row) {
-  return ws + (u64)row * threads;
+// Workspace access: one buffer descriptor per kangaroo slot (base = first row of the slot, range = the slot's
+// R rows, so a wrong offset is dropped by the hardware bounds check instead of faulting), the row as a
+// uniform SGPR offset and the lane as a constant VGPR byte offset: no per-access address arithmetic on the VALU.
+typedef __amdgpu_buffer_rsrc_t ws_rsrc;
+__device__ __forceinline__ ws_rsrc ws_slot(u32 *ws, u32 threads, u32 rows_per_slot, u32 id) {
+  return __builtin_amdgcn_make_buffer_rsrc(ws + (u64)id * rows_per_slot * threads, 0, (int)(rows_per_slot * threads * 4u),
+                                           0x00020000);
 }
-__device__ __forceinline__ u32 ld_lane(const u32 *row, u32 off_bytes) {
-  return *(const u32 *)((const char *)row + off_bytes);
+__device__ __forceinline__ u32 ld_row(ws_rsrc rs, u32 off_bytes, u32 row, u32 row_bytes) {
+  return __builtin_amdgcn_raw_buffer_load_b32(rs, off_bytes, row * row_bytes, 0);
 }
-__device__ __forceinline__ void st_lane(u32 *row, u32 off_bytes, u32 v) { *(u32 *)((char *)row + off_bytes) = v; }
+__device__ __forceinline__ void st_row(ws_rsrc rs, u32 off_bytes, u32 row, u32 row_bytes, u32 v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, rs, off_bytes, row * row_bytes, 0);
+}
 
 template <int DW, int W>
 __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArgs sa) {
@@ -66,19 +72,31 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   const u32 threads = a.threads;
   u32 *ws = sa.ws;
 
+  const u32 rowb = threads * 4u;  // bytes per workspace row
   auto load_rec = [&](StreamRec<DW> &r, u32 id) {
-    const u32 base = id * R;
+    const ws_rsrc rs = ws_slot(ws, threads, R, id);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.x.l[i] = ld_lane(ws_row(ws, threads, base + i), off);
+    for (int i = 0; i < 9; ++i) r.x.l[i] = ld_row(rs, off, i, rowb);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.y.l[i] = ld_lane(ws_row(ws, threads, base + 9 + i), off);
+    for (int i = 0; i < 9; ++i) r.y.l[i] = ld_row(rs, off, 9 + i, rowb);
 #pragma unroll
-    for (int i = 0; i < DW; ++i) r.dl.w[i] = ld_lane(ws_row(ws, threads, base + 18 + i), off);
+    for (int i = 0; i < DW; ++i) r.dl.w[i] = ld_row(rs, off, 18 + i, rowb);
   };
   auto load_p = [&](fe &q, u32 id) {
-    const u32 base = id * R + 18 + DW;
+    const ws_rsrc rs = ws_slot(ws, threads, R, id);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) q.l[i] = ld_lane(ws_row(ws, threads, base + i), off);
+    for (int i = 0; i < 9; ++i) q.l[i] = ld_row(rs, off, 18 + DW + i, rowb);
+  };
+  auto store_all = [&](u32 id, const fe &x, const fe &y, const dlt<DW> &dl, const fe &pp) {
+    const ws_rsrc rs = ws_slot(ws, threads, R, id);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st_row(rs, off, i, rowb, x.l[i]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st_row(rs, off, 9 + i, rowb, y.l[i]);
+#pragma unroll
+    for (int i = 0; i < DW; ++i) st_row(rs, off, 18 + i, rowb, dl.w[i]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) st_row(rs, off, 18 + DW + i, rowb, pp.l[i]);
   };
 
   // ---- prologue: X/Y planes -> workspace, zero deltas, prefix products of the first step's dx (ascending) ----
@@ -110,15 +128,10 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     for (int i = 0; i < 9; ++i) jx.l[i] = row[i];
     fe_sub_wide(dx, x, jx);
     fe_mul(acc, dx, acc);
-    const u32 base = k * R;
+    dlt<DW> zero;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + i), off, x.l[i]);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + 9 + i), off, y.l[i]);
-#pragma unroll
-    for (int i = 0; i < DW; ++i) st_lane((u32 *)ws_row(ws, threads, base + 18 + i), off, 0u);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + 18 + DW + i), off, acc.l[i]);
+    for (int i = 0; i < DW; ++i) zero.w[i] = 0u;
+    store_all(k, x, y, zero, acc);
   }
 
   // ---- steps: pass `run` visits the ids descending when run is even (the prologue went up), ascending when odd ----
@@ -195,17 +208,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
         fe_sub_wide(dx2, rx, jx2);
         fe_mul(acc, dx2, acc);
       }
-      {
-        const u32 base = id * R;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + i), off, rx.l[i]);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + 9 + i), off, ry.l[i]);
-#pragma unroll
-        for (int i = 0; i < DW; ++i) st_lane((u32 *)ws_row(ws, threads, base + 18 + i), off, cur.dl.w[i]);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) st_lane((u32 *)ws_row(ws, threads, base + 18 + DW + i), off, acc.l[i]);
-      }
+      store_all(id, rx, ry, cur.dl, acc);
 
       // distinguished point: (x.bits64[3] & dpMask) == 0   (math/gpu/compute.h:54)
       const u32 top_hi = (rx.l[8] << 8) | (rx.l[7] >> 21);

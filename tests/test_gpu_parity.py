@@ -11,16 +11,16 @@ from gpu_common import dp_multiset, make_case, oracle_dps
 pytestmark = pytest.mark.gpu
 
 
-def _engine(groups, per_group, case, nb_run=None, k=None, u=None, w=None):
+def _engine(groups, per_group, case, nb_run=None, k=None, u=None, w=None, mode=None):
     from kangaroo_amd import GPUEngine
 
-    for name, val in (("KG_K", k), ("KG_U", u), ("KG_W", w)):
+    for name, val in (("KG_K", k), ("KG_U", u), ("KG_W", w), ("KG_MODE", mode)):
         if val is not None:
             os.environ[name] = str(val)
     try:
         e = GPUEngine(groups, per_group, 0, 65536 * 2)
     finally:
-        for name in ("KG_K", "KG_U", "KG_W"):
+        for name in ("KG_K", "KG_U", "KG_W", "KG_MODE"):
             os.environ.pop(name, None)
     e.SetWildOffset(case["width"] >> 1)  # core/kangaroo.cpp:436
     e.SetParams(case["dp_mask"], case["jd"], case["jx"], case["jy"])
@@ -30,17 +30,22 @@ def _engine(groups, per_group, case, nb_run=None, k=None, u=None, w=None):
     return e
 
 
-# (kangaroos per lane, window U: 0 = fully unrolled kernel, waves/SIMD the allocation allows)
-VARIANTS = [(1, 0, 2), (4, 0, 2), (8, 0, 2), (8, 0, 1), (12, 0, 1), (8, 4, 2), (12, 4, 1), (16, 4, 1), (16, 2, 1)]
+# register-resident kernels: (mode, kangaroos per lane, window U: 0 = fully unrolled kernel, waves/SIMD allowed)
+# streaming kernel: (mode, kangaroos per lane, -, waves/SIMD); 64 per lane leaves half of the only workgroup padding
+VARIANTS = [("reg", 1, 0, 2), ("reg", 4, 0, 2), ("reg", 8, 0, 2), ("reg", 8, 0, 1), ("reg", 12, 0, 1), ("reg", 8, 4, 2),
+            ("reg", 12, 4, 1), ("reg", 16, 4, 1), ("reg", 16, 2, 1),
+            ("stream", 1, None, 2), ("stream", 2, None, 2), ("stream", 5, None, 3), ("stream", 16, None, 2),
+            ("stream", 64, None, 2), ("stream", 10, None, 1)]
 
 
-@pytest.mark.parametrize("k,u,w", VARIANTS)
-def test_dp_stream_and_state_match_oracle(k, u, w):
+@pytest.mark.parametrize("mode,k,u,w", VARIANTS)
+def test_dp_stream_and_state_match_oracle(mode, k, u, w):
     """BASELINE config 2 in miniature: 64-bit range, same seed -> same DPs as the CPU walk.
-    Odd and even step counts per launch exercise both pass directions of the rotating kernel."""
+    Odd and even step counts per launch exercise both pass directions of the fused pass."""
     case = make_case(64, 128 * 2 * 32, seed=1000 + k, dp_bits=6)
-    e = _engine(2, 32, case, nb_run=64, k=k, u=u, w=w)
+    e = _engine(2, 32, case, nb_run=64, k=k, u=u, w=w, mode=mode)
     assert e.KernelInfo()["k_per_lane"] == k
+    assert ("stream" in e.KernelName()) == (mode == "stream")
     px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
     e.callKernel()
     for launch in range(3):
@@ -61,10 +66,11 @@ def test_dp_stream_and_state_match_oracle(k, u, w):
     e.close()
 
 
-def test_default_nb_run_256_and_125_bit_range():
+@pytest.mark.parametrize("mode", ["stream", "reg"])
+def test_default_nb_run_256_and_125_bit_range(mode):
     """NB_RUN = 256 (constants.h:21) with the benchmark's 125-bit jump table (3-word distance delta)."""
     case = make_case(125, 128 * 1 * 64, seed=77, dp_bits=8)
-    e = _engine(1, 64, case)
+    e = _engine(1, 64, case, mode=mode)
     px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
     e.callKernel()
     got = dp_multiset(e.Collect())
@@ -75,10 +81,11 @@ def test_default_nb_run_256_and_125_bit_range():
     e.close()
 
 
-def test_wide_jump_distances_use_full_width_delta():
+@pytest.mark.parametrize("mode", ["stream", "reg"])
+def test_wide_jump_distances_use_full_width_delta(mode):
     """Jump distances wider than 96 bits select the 8-word delta kernel; distances stay exact."""
     case = make_case(250, 128 * 1 * 64, seed=5, dp_bits=5)
-    e = _engine(1, 64, case, nb_run=32)
+    e = _engine(1, 64, case, nb_run=32, mode=mode)
     assert e.KernelInfo()["delta_words"] == 8
     px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
     e.callKernel()
@@ -88,10 +95,11 @@ def test_wide_jump_distances_use_full_width_delta():
     e.close()
 
 
-def test_set_kangaroo_between_launches():
+@pytest.mark.parametrize("mode", ["stream", "reg"])
+def test_set_kangaroo_between_launches(mode):
     """SetKangaroo (dead-kangaroo reset, core/kangaroo.cpp:484-485) lands before the next launch."""
     case = make_case(64, 128 * 1 * 64, seed=9, dp_bits=4)
-    e = _engine(1, 64, case, nb_run=16)
+    e = _engine(1, 64, case, nb_run=16, mode=mode)
     px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
     e.callKernel()
     items = e.Launch()  # launch 2 already queued
@@ -108,12 +116,13 @@ def test_set_kangaroo_between_launches():
     e.close()
 
 
-def test_dp_zero_bits_every_point_and_overflow_report():
+@pytest.mark.parametrize("mode", ["stream", "reg"])
+def test_dp_zero_bits_every_point_and_overflow_report(mode):
     """dpSize = 0: every jump is a DP (core/kangaroo.cpp:110-120).  Capacity overflow is reported, not hidden."""
     from kangaroo_amd import KgError
 
     case = make_case(64, 128 * 1 * 64, seed=3, dp_bits=0)
-    e = _engine(1, 64, case, nb_run=2)
+    e = _engine(1, 64, case, nb_run=2, mode=mode)
     px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
     e.callKernel()
     assert dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 2)
