@@ -522,7 +522,7 @@ extern "C" int kg_kick(kg_engine *e) {
   const StreamVariant *sv = e->streaming ? find_stream_variant(e->DW) : nullptr;
   if (!v && !sv) return fail(KG_ERR_STATE, "GPUEngine: Kernel: no kernel variant for this configuration");
   if (sv) {
-    const size_t need = (size_t)(27 + e->DW) * (size_t)e->K * (size_t)e->threads * sizeof(u32);
+    const size_t need = (size_t)ws_groups(e->DW) * 3 * (size_t)e->K * (size_t)e->threads * sizeof(u32);
     if (need > e->ws_bytes) {
       HIPCHK(hipStreamSynchronize(e->stream));
       if (e->ws) (void)hipFree(e->ws);

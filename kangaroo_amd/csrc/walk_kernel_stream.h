@@ -10,10 +10,10 @@
 // traffic: 4 * (2 * (18 + DW) + 2 * 9) bytes per jump (240 B for DW = 3), all of it lane-contiguous
 // dword rows.
 //
-// Workspace (engine-private, HBM): rows of `threads` u32; kangaroo slot k of lane T uses rows
-//   k * R + 0..8   x limbs        k * R + 9..17        y limbs
-//   k * R + 18..   DW delta words k * R + 18 + DW ..   9 limbs of the stored partial product P[k]
-// with R = 27 + DW.  The prologue converts X/Y planes into the workspace, the epilogue converts back and
+// Workspace (engine-private, HBM): a kangaroo slot is R = 27 + DW words per lane
+//   words 0..8 x limbs, 9..17 y limbs, 18..18+DW-1 delta words, then the 9 limbs of the stored partial product P[k],
+// cut into G = ceil(R / 3) groups of three words; group g of slot k is a row of `threads` 12-byte entries at
+// row index k * G + g, so that one buffer_load/store_dwordx3 moves 768 contiguous bytes per wavefront.  The prologue converts X/Y planes into the workspace, the epilogue converts back and
 // adds the deltas to D, so the engine's resident format (walk_kernel.h) is unchanged.
 //
 // The step itself is the fused pass of walk_kernel_rot.h: same arithmetic, same results.
@@ -38,21 +38,40 @@ struct StreamRec {
 // R rows, so a wrong offset is dropped by the hardware bounds check instead of faulting), the row as a
 // uniform SGPR offset and the lane as a constant VGPR byte offset: no per-access address arithmetic on the VALU.
 typedef __amdgpu_buffer_rsrc_t ws_rsrc;
-__device__ __forceinline__ ws_rsrc ws_slot(u32 *ws, u32 threads, u32 rows_per_slot, u32 id) {
-  return __builtin_amdgcn_make_buffer_rsrc(ws + (u64)id * rows_per_slot * threads, 0, (int)(rows_per_slot * threads * 4u),
-                                           0x00020000);
+typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+constexpr u32 ws_groups(int DW) { return (27 + DW + 2) / 3; }
+__device__ __forceinline__ ws_rsrc ws_slot(u32 *ws, u32 threads, u32 groups, u32 id) {
+  return __builtin_amdgcn_make_buffer_rsrc(ws + (u64)id * groups * 3u * threads, 0, (int)(groups * threads * 12u), 0x00020000);
 }
-__device__ __forceinline__ u32 ld_row(ws_rsrc rs, u32 off_bytes, u32 row, u32 row_bytes) {
-  return __builtin_amdgcn_raw_buffer_load_b32(rs, off_bytes, row * row_bytes, 0);
+// words [FIRST, FIRST + N) of a slot -> dst[0..N)
+template <int FIRST, int N>
+__device__ __forceinline__ void ws_load(u32 *dst, ws_rsrc rs, u32 off_bytes, u32 row_bytes) {
+  constexpr int G0 = FIRST / 3, G1 = (FIRST + N - 1) / 3;
+#pragma unroll
+  for (int g = G0; g <= G1; ++g) {
+    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, off_bytes, (u32)g * row_bytes, 0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int w = 3 * g + c - FIRST;
+      if (w >= 0 && w < N) dst[w] = v[c];
+    }
+  }
 }
-__device__ __forceinline__ void st_row(ws_rsrc rs, u32 off_bytes, u32 row, u32 row_bytes, u32 v) {
-  __builtin_amdgcn_raw_buffer_store_b32(v, rs, off_bytes, row * row_bytes, 0);
+// groups [G0, G1] of a slot <- src, where src[i] is word 3 * G0 + i of the slot
+template <int G0, int G1>
+__device__ __forceinline__ void ws_store(ws_rsrc rs, u32 off_bytes, u32 row_bytes, const u32 *src) {
+#pragma unroll
+  for (int g = G0; g <= G1; ++g) {
+    u32x3 v;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = src[3 * (g - G0) + c];
+    __builtin_amdgcn_raw_buffer_store_b96(v, rs, off_bytes, (u32)g * row_bytes, 0);
+  }
 }
 
 template <int DW, int W>
 __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArgs sa) {
   const WalkArgs &a = sa.a;
-  constexpr u32 R = 27 + DW;
   extern __shared__ u32 lds[];
   u32 *jt = lds;                           // [64][JT_STRIDE]
   u32 *jdist = lds + NB_JUMP * JT_STRIDE;  // [64][DW]
@@ -66,37 +85,44 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   __syncthreads();
 
   const u32 Tl = blockIdx.x * WALK_BLOCK + tid;  // lane index < threads
-  const u32 off = Tl * 4u;                       // byte offset inside a workspace row
+  const u32 off = Tl * 12u;                      // byte offset inside a workspace row
   const u64 T = Tl;
   const u32 K = sa.K;
   const u32 threads = a.threads;
   u32 *ws = sa.ws;
+  constexpr u32 G = ws_groups(DW);
+  const u32 rowb = threads * 12u;  // bytes per workspace row
 
-  const u32 rowb = threads * 4u;  // bytes per workspace row
   auto load_rec = [&](StreamRec<DW> &r, u32 id) {
-    const ws_rsrc rs = ws_slot(ws, threads, R, id);
+    const ws_rsrc rs = ws_slot(ws, threads, G, id);
+    u32 wv[18 + DW];
+    ws_load<0, 18 + DW>(wv, rs, off, rowb);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.x.l[i] = ld_row(rs, off, i, rowb);
+    for (int i = 0; i < 9; ++i) {
+      r.x.l[i] = wv[i];
+      r.y.l[i] = wv[9 + i];
+    }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) r.y.l[i] = ld_row(rs, off, 9 + i, rowb);
-#pragma unroll
-    for (int i = 0; i < DW; ++i) r.dl.w[i] = ld_row(rs, off, 18 + i, rowb);
+    for (int i = 0; i < DW; ++i) r.dl.w[i] = wv[18 + i];
   };
   auto load_p = [&](fe &q, u32 id) {
-    const ws_rsrc rs = ws_slot(ws, threads, R, id);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) q.l[i] = ld_row(rs, off, 18 + DW + i, rowb);
+    const ws_rsrc rs = ws_slot(ws, threads, G, id);
+    ws_load<18 + DW, 9>(q.l, rs, off, rowb);
   };
   auto store_all = [&](u32 id, const fe &x, const fe &y, const dlt<DW> &dl, const fe &pp) {
-    const ws_rsrc rs = ws_slot(ws, threads, R, id);
+    const ws_rsrc rs = ws_slot(ws, threads, G, id);
+    u32 wv[3 * G];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) st_row(rs, off, i, rowb, x.l[i]);
+    for (int i = 0; i < 9; ++i) {
+      wv[i] = x.l[i];
+      wv[9 + i] = y.l[i];
+      wv[18 + DW + i] = pp.l[i];
+    }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) st_row(rs, off, 9 + i, rowb, y.l[i]);
+    for (int i = 0; i < DW; ++i) wv[18 + i] = dl.w[i];
 #pragma unroll
-    for (int i = 0; i < DW; ++i) st_row(rs, off, 18 + i, rowb, dl.w[i]);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) st_row(rs, off, 18 + DW + i, rowb, pp.l[i]);
+    for (int i = 27 + DW; i < (int)(3 * G); ++i) wv[i] = 0u;
+    ws_store<0, G - 1>(rs, off, rowb, wv);
   };
 
   // ---- prologue: X/Y planes -> workspace, zero deltas, prefix products of the first step's dx (ascending) ----
