@@ -141,10 +141,20 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
             pmc = json.load(f)
-        if pmc["kangaroos_per_gpu"] == n and pmc["nb_run"] == args.nb_run:
+        if pmc["kangaroos_per_gpu"] == n and pmc["nb_run"] == args.nb_run and pmc["kernel"] == eng.KernelName():
             traffic = pmc["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
+    # HBM side of the same launch.  The streaming kernel keeps the herd in HBM during the launch: per jump it
+    # reads and writes one workspace slot of G = ceil((27 + DW) / 3) 12-byte groups; the
+    # register-resident kernels only load/store the herd once per launch.
+    name = eng.KernelName()
+    if "stream" in name:
+        groups = (27 + info["delta_words"] + 2) // 3
+        bytes_per_jump = 2 * groups * 12 + STATE_BYTES_PER_KANGAROO / args.nb_run
+    else:
+        bytes_per_jump = STATE_BYTES_PER_KANGAROO / args.nb_run
+    hbm_gbps = kernel_jumps_per_s * bytes_per_jump / 1e9
     out = {
         "metric": "kangaroo jumps/sec (secp256k1 affine jump incl. grouped inversion, DP test and append)",
         "value": value, "unit": "jumps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -158,8 +168,11 @@ def main():
                      "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_PER_S, "traffic": traffic,
                      "kernel": eng.KernelName(), "kernel_ms_avg": avg_kernel_ms,
                      "mad32_per_jump": MAD32_PER_JUMP, "kernel_jumps_per_s": kernel_jumps_per_s,
-                     "hbm_state_GBps": n * STATE_BYTES_PER_KANGAROO / (avg_kernel_ms * 1e-3) / 1e9,
-                     "note": "bound is VALU integer multiply issue (SURVEY §8d), not HBM/MFMA; HBM traffic is 0.75 B/jump"},
+                     "hbm": {"bytes_per_jump": bytes_per_jump, "achieved_GBps": hbm_gbps, "peak_GBps": 8000.0,
+                             "frac": hbm_gbps / 8000.0},
+                     "note": "primary bound per SURVEY §8d is VALU integer multiply issue (frac above); the streaming "
+                             "kernel also moves bytes_per_jump through HBM, see hbm.frac; traffic = PMC HBM bytes per "
+                             "launch (profiles/r01_pmc_hbm.json)"},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
