@@ -4,7 +4,7 @@
 Workload (one GPU): range [0, 2^125-1] (rangePower 125 -> 63-bit jumps), jump table from the fixed seed
 0x600DCAFE, DP mask of 32 bits (no solve expected, DP traffic negligible), default grid 2*CUs x 128 ->
 8.4 M kangaroos per GPU, NB_RUN = 256.  A "step" is one GPUEngine::Launch = nbKangaroo * NB_RUN jumps.
-The herd is synthetic (valid curve points d_i*G, built on the host by the product's own helper) and is
+The herd is a seeded CreateHerd herd for a synthetic key (distances on the host, points on the GPU) and is
 resident in HBM before the timed region starts.  N > 1: one process per GPU, disjoint herds, no
 collective in the jump path (weak scaling); torch.distributed is used for barrier / max only.
 
@@ -96,13 +96,16 @@ def main():
     dp_mask = int(cfg[768])
     wild = cfg[769:773]
 
-    d0, stride = dist.herd_shard(rank, world, n)
-    px, py, d = host.synthetic_herd(n, d0=d0, stride=stride)
+    # herd: CreateHerd's distances (core/kangaroo.cpp:531-548) from a per-rank seed, so the ranks' herds are
+    # disjoint random samples; the points d*G (+ key for the wild half) are computed on the GPU
+    width = (1 << 125) - 1
+    key = host.ec_mul_g(0x0A5B3C1D2E7F9081726354453627180F % width)
+    d = host.herd_distances(host.Rng(0x5EED0000 + rank), 125, width, n, 0)
     eng.SetWildOffset(wild)
     eng.SetParams(dp_mask, jd, jx, jy)
     eng.SetNbRun(args.nb_run)
-    eng.SetKangaroos(px, py, d)
-    del px, py, d
+    eng.HerdFromDistances(d, key)
+    del d
 
     # warmup
     eng.callKernel()

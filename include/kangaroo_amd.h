@@ -84,6 +84,13 @@ int kg_set_params(kg_engine *e, uint64_t dp_mask, const uint64_t *jump_dist, con
 /* Replaces GPUEngine::SetKangaroos (engine.cu:281-326): n = kg_nb_kangaroo(e) entries of 4 limbs
  * each, host index order; x, y must be canonical affine coordinates. */
 int kg_set_kangaroos(kg_engine *e, const uint64_t *px, const uint64_t *py, const uint64_t *d, uint64_t n);
+/* Herd creation on the GPU: P_i = d_i * G, plus the search key (key_x, key_y) for odd (wild) i; then as
+ * kg_set_kangaroos with those points.  Replaces the CPU point computation of Kangaroo::CreateHerd
+ * (core/kangaroo.cpp:549-571: ComputePublicKeys + AddDirect) in front of GPUEngine::SetKangaroos; d as
+ * produced by kgh_herd_distances or the reference's own loop (core/kangaroo.cpp:531-548).  Pass an all-zero
+ * key to get plain d_i * G for every i.  The points can be read back with kg_get_kangaroos. */
+int kg_herd_from_distances(kg_engine *e, const uint64_t *d, uint64_t n, const uint64_t key_x[4],
+                           const uint64_t key_y[4]);
 /* Replaces GPUEngine::GetKangaroos (engine.cu:328-383).  Waits for the launch in flight. */
 int kg_get_kangaroos(kg_engine *e, uint64_t *px, uint64_t *py, uint64_t *d, uint64_t n);
 /* Replaces GPUEngine::SetKangaroo (engine.cu:385-425): overwrite one kangaroo.  Ordered on the

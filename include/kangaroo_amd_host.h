@@ -45,6 +45,13 @@ uint32_t kgh_rng_next(kgh_rng *r);
 int kgh_create_herd(kgh_rng *r, int range_power, const uint64_t range_width[4], const uint64_t key_x[4],
                     const uint64_t key_y[4], int first_type, size_t n, uint64_t *px, uint64_t *py, uint64_t *d);
 
+/* The distance half of CreateHerd alone (same RNG draws, core/kangaroo.cpp:531-548): the points can then be
+ * computed on the GPU with kg_herd_from_distances (kangaroo_amd.h). */
+int kgh_herd_distances(kgh_rng *r, int range_power, const uint64_t range_width[4], int first_type, size_t n,
+                       uint64_t *d);
+/* Fixed-base comb table for the GPU herd kernel: tab[32][256][18] limbs, plus the start point. */
+int kgh_comb_table(uint32_t *tab, uint64_t start_x[4], uint64_t start_y[4]);
+
 /* Fast synthetic herd for throughput runs (SURVEY §8d "any valid curve points"): d_i = d0 + i*stride
  * (mod n), P_i = d_i*G, built with batched affine additions (about 1-2 M points/s per host core).
  * No counterpart in the reference. */

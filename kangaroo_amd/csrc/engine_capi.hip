@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,8 @@
 #include "walk_kernel.h"
 #include "walk_kernel_rot.h"
 #include "walk_kernel_stream.h"
+#include "herd_kernel.h"
+#include "../../include/kangaroo_amd_host.h"
 
 using namespace kg;
 
@@ -465,6 +468,112 @@ extern "C" int kg_set_kangaroos(kg_engine *e, const uint64_t *px, const uint64_t
   }
   e->herd_set = true;
   return KG_OK;
+}
+
+// ---- herd creation on the GPU -------------------------------------------------------------
+namespace {
+std::once_flag g_comb_once;
+std::vector<u32> g_comb_tab;  // [32][256][18]
+u64 g_comb_sx[4], g_comb_sy[4];
+void to_limbs18(u32 *dst, const u64 x[4], const u64 y[4]) {
+  for (int c = 0; c < 2; ++c) {
+    const u64 *src = c ? y : x;
+    u32 w[8];
+    for (int i = 0; i < 4; ++i) {
+      w[2 * i] = (u32)src[i];
+      w[2 * i + 1] = (u32)(src[i] >> 32);
+    }
+    fe f;
+    fe_from_words(f, w);
+    for (int i = 0; i < 9; ++i) dst[9 * c + i] = f.l[i];
+  }
+}
+}  // namespace
+
+extern "C" int kg_herd_from_distances(kg_engine *e, const uint64_t *d, uint64_t n, const uint64_t key_x[4],
+                                      const uint64_t key_y[4]) {
+  if (!e || !d || !key_x || !key_y) return fail(KG_ERR_ARG, "kg_herd_from_distances: bad argument");
+  if (n != e->n) return fail(KG_ERR_ARG, "kg_herd_from_distances: n must equal kg_nb_kangaroo()");
+  if (bind(e) != KG_OK || wait_idle(e) != KG_OK) return KG_ERR_HIP;
+  std::call_once(g_comb_once, [] {
+    g_comb_tab.resize((size_t)HERD_WINDOWS * 256 * 18);
+    kgh_comb_table(g_comb_tab.data(), g_comb_sx, g_comb_sy);
+  });
+  HerdArgs a;
+  to_limbs18(a.start[0], g_comb_sx, g_comb_sy);
+  const bool have_key = (key_x[0] | key_x[1] | key_x[2] | key_x[3] | key_y[0] | key_y[1] | key_y[2] | key_y[3]) != 0;
+  if (have_key) {
+    u64 wx[4], wy[4];
+    if (kgh_ec_add(wx, wy, g_comb_sx, g_comb_sy, key_x, key_y) != 0)
+      return fail(KG_ERR_ARG, "kg_herd_from_distances: key collides with the comb start point");
+    to_limbs18(a.start[1], wx, wy);
+  } else {
+    memcpy(a.start[1], a.start[0], sizeof a.start[0]);
+  }
+  // geometry of its own: about two waves per SIMD, at most 64 points per lane
+  const u64 lanes_target = (u64)e->cus * 4 * 64 * 2;
+  u64 K = std::min<u64>(std::max<u64>((n + lanes_target - 1) / lanes_target, 1), 64);
+  u64 lanes = ((n + K - 1) / K + WALK_BLOCK - 1) / WALK_BLOCK * WALK_BLOCK;
+  u32 *tab_dev = nullptr, *ws = nullptr;
+  u64 *k_dev = nullptr;
+  int rc = KG_OK;
+  auto cleanup = [&]() {
+    if (tab_dev) (void)hipFree(tab_dev);
+    if (ws) (void)hipFree(ws);
+    if (k_dev) (void)hipFree(k_dev);
+  };
+#define HT(expr)                                                                                         \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) {                                                                              \
+      cleanup();                                                                                         \
+      return fail(KG_ERR_HIP, std::string("GPUEngine: ") + #expr + ": " + hipGetErrorString(_e));        \
+    }                                                                                                    \
+  } while (0)
+  HT(hipMalloc((void **)&tab_dev, g_comb_tab.size() * sizeof(u32)));
+  HT(hipMalloc((void **)&k_dev, (size_t)n * 32));
+  HT(hipMalloc((void **)&ws, (size_t)K * 27 * lanes * sizeof(u32)));
+  HT(hipMemcpyAsync(tab_dev, g_comb_tab.data(), g_comb_tab.size() * sizeof(u32), hipMemcpyHostToDevice, e->stream));
+  HT(hipMemcpyAsync(k_dev, d, (size_t)n * 32, hipMemcpyHostToDevice, e->stream));
+  a.tab = tab_dev;
+  a.k = k_dev;
+  a.n = n;
+  a.lanes = (u32)lanes;
+  a.K = (u32)K;
+  a.ws = ws;
+  a.X = e->X;
+  a.Y = e->Y;
+  a.cap = e->cap;
+  hipLaunchKernelGGL(kg_herd_kernel, dim3((u32)(lanes / WALK_BLOCK)), dim3(WALK_BLOCK), 0, e->stream, a);
+  HT(hipGetLastError());
+  // distances: wild offset applied on the host (engine.cu:305-308), planes uploaded in chunks
+  {
+    const size_t chunk = e->stage_elems;
+    u64 *sd = e->stage;
+    for (u64 p0 = 0; p0 < n; p0 += chunk) {
+      const u64 cnt = std::min<u64>(chunk, n - p0);
+      for (u64 i = 0; i < cnt; ++i) {
+        const u64 p = p0 + i;
+        u64 dd[4];
+        if (p & 1) order_add(dd, d + 4 * p, e->wild);
+        else memcpy(dd, d + 4 * p, 32);
+        for (int w = 0; w < 4; ++w) sd[(size_t)w * chunk + i] = dd[w];
+      }
+      for (int w = 0; w < 4; ++w)
+        HT(hipMemcpyAsync(e->D + (u64)w * e->cap + p0, sd + (size_t)w * chunk, cnt * 8, hipMemcpyHostToDevice, e->stream));
+      HT(hipStreamSynchronize(e->stream));
+    }
+  }
+  if (e->cap > n) {
+    const u64 pad = e->cap - n;
+    hipLaunchKernelGGL(kg_pad_kernel, dim3((u32)((pad + 255) / 256)), dim3(256), 0, e->stream, e->X, e->Y, e->D, e->cap, n);
+    HT(hipGetLastError());
+  }
+  HT(hipStreamSynchronize(e->stream));
+#undef HT
+  cleanup();
+  e->herd_set = true;
+  return rc;
 }
 
 extern "C" int kg_get_kangaroos(kg_engine *e, uint64_t *px, uint64_t *py, uint64_t *d, uint64_t n) {

@@ -439,9 +439,9 @@ kgh_rng *kgh_rng_new(uint32_t seed) {
 void kgh_rng_free(kgh_rng *r) { delete r; }
 uint32_t kgh_rng_next(kgh_rng *r) { return (uint32_t)r->g(); }
 
-int kgh_create_herd(kgh_rng *r, int range_power, const uint64_t range_width[4], const uint64_t key_x[4],
-                    const uint64_t key_y[4], int first_type, size_t n, uint64_t *px, uint64_t *py, uint64_t *d) {
-  if (!r || !px || !py || !d) return -1;
+int kgh_herd_distances(kgh_rng *r, int range_power, const uint64_t range_width[4], int first_type, size_t n,
+                       uint64_t *d) {
+  if (!r || !d) return -1;
   const U256 w8 = shr(load(range_width), 3);
   const int off = first_type % 2;
   for (size_t j = 0; j < n; ++j) {
@@ -455,6 +455,14 @@ int kgh_create_herd(kgh_rng *r, int range_power, const uint64_t range_width[4], 
     }
     store(d + 4 * j, v);
   }
+  return 0;
+}
+
+int kgh_create_herd(kgh_rng *r, int range_power, const uint64_t range_width[4], const uint64_t key_x[4],
+                    const uint64_t key_y[4], int first_type, size_t n, uint64_t *px, uint64_t *py, uint64_t *d) {
+  if (!r || !px || !py || !d) return -1;
+  const int off = first_type % 2;
+  kgh_herd_distances(r, range_power, range_width, first_type, n, d);
   mul_g_batch(d, n, px, py);
   // wild kangaroos start at key + d*G: one batched inversion over the wild subset
   const Aff key{load(key_x), load(key_y), false};
@@ -476,6 +484,53 @@ int kgh_create_herd(kgh_rng *r, int range_power, const uint64_t range_width[4], 
     store(px + 4 * j, rx);
     store(py + 4 * j, ry);
   }
+  return 0;
+}
+
+// Fixed-base comb for the GPU herd kernel (kangaroo_amd/csrc/herd_kernel.h): 32 windows of 8 bits.
+// Entry (w, j) = (j * 2^(8w) + c_w) * G with fixed offsets c_w, and the start point S = -(sum c_w) * G, so
+// that S + sum_w T[w][digit_w(k)] = k * G with an addition in EVERY window (no "digit 0: skip" case and no
+// point at infinity on the device).  Points as 9+9 limbs of 29 bits (fe29.h).
+int kgh_comb_table(uint32_t *tab, uint64_t start_x[4], uint64_t start_y[4]) {
+  if (!tab || !start_x || !start_y) return -1;
+  const size_t cnt = 32 * 256;
+  std::vector<u64> k(4 * cnt), x(4 * cnt), y(4 * cnt);
+  U256 sum = {{0, 0, 0, 0}};
+  u64 sm = 0x4B616E6761726F6FULL;  // splitmix64 stream for the offsets
+  auto next = [&]() {
+    sm += 0x9E3779B97F4A7C15ULL;
+    u64 z = sm;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+  };
+  for (int w = 0; w < 32; ++w) {
+    U256 c = {{next(), next(), next(), next() >> 1}};  // < 2^255 < n
+    sum = mod_add(sum, c, ORD);
+    for (int j = 0; j < 256; ++j) {
+      U256 v = {{0, 0, 0, 0}};
+      v.v[w / 8] = (u64)j << (8 * (w % 8));
+      v = reduce_once(v, ORD);
+      store(&k[4 * (size_t)(w * 256 + j)], mod_add(v, c, ORD));
+    }
+  }
+  mul_g_batch(k.data(), cnt, x.data(), y.data());
+  for (size_t e = 0; e < cnt; ++e) {
+    for (int c = 0; c < 2; ++c) {
+      const u64 *src = (c == 0 ? x.data() : y.data()) + 4 * e;
+      uint32_t w8[8];
+      for (int i = 0; i < 4; ++i) {
+        w8[2 * i] = (uint32_t)src[i];
+        w8[2 * i + 1] = (uint32_t)(src[i] >> 32);
+      }
+      kg::fe f;
+      kg::fe_from_words(f, w8);
+      for (int i = 0; i < 9; ++i) tab[e * 18 + 9 * c + i] = f.l[i];
+    }
+  }
+  const Aff S = mul_g(mod_neg(sum, ORD));
+  store(start_x, S.x);
+  store(start_y, S.y);
   return 0;
 }
 

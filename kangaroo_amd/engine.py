@@ -63,6 +63,7 @@ def load_library():
         "kg_set_params": ([H, C.c_uint64, _u64p, _u64p, _u64p], C.c_int),
         "kg_set_kangaroos": ([H, _u64p, _u64p, _u64p, C.c_uint64], C.c_int),
         "kg_get_kangaroos": ([H, _u64p, _u64p, _u64p, C.c_uint64], C.c_int),
+        "kg_herd_from_distances": ([H, _u64p, C.c_uint64, _u64p, _u64p], C.c_int),
         "kg_set_kangaroo": ([H, C.c_uint64, _u64p, _u64p, _u64p], C.c_int),
         "kg_set_nb_run": ([H, C.c_uint32], C.c_int),
         "kg_kick": ([H], C.c_int),
@@ -89,7 +90,7 @@ def load_library():
 ABI_SYMBOLS = [
     "kg_device_count", "kg_default_grid", "kg_create", "kg_destroy", "kg_device_name", "kg_memory_bytes",
     "kg_nb_thread", "kg_group_size", "kg_nb_kangaroo", "kg_set_wild_offset", "kg_set_params", "kg_set_kangaroos",
-    "kg_get_kangaroos", "kg_set_kangaroo", "kg_set_nb_run", "kg_kick", "kg_collect", "kg_launch",
+    "kg_get_kangaroos", "kg_herd_from_distances", "kg_set_kangaroo", "kg_set_nb_run", "kg_kick", "kg_collect", "kg_launch",
     "kg_kick_and_wait", "kg_last_kernel_ms", "kg_kernel_info", "kg_kernel_name", "kg_alloc_pinned", "kg_free_pinned",
     "kg_print_device_info", "kg_last_error", "kg_version",
 ]
@@ -205,6 +206,12 @@ class GPUEngine:
         n = self.nbKangaroo
         a, b, c = _arr(px, n), _arr(py, n), _arr(d, n)
         _chk(self._L.kg_set_kangaroos(self._h, _p(a), _p(b), _p(c), n))
+
+    def HerdFromDistances(self, d, key=(0, 0)):
+        """Points computed on the GPU: d_i*G (+ key for odd i), then as SetKangaroos (kg_herd_from_distances)."""
+        n = self.nbKangaroo
+        dd = _arr(d, n)
+        _chk(self._L.kg_herd_from_distances(self._h, _p(dd), n, _p(_limbs(key[0])), _p(_limbs(key[1]))))
 
     def GetKangaroos(self):
         n = self.nbKangaroo

@@ -11,7 +11,7 @@ _ready = False
 
 HOST_SYMBOLS = [
     "kgh_ec_mul_g", "kgh_ec_mul_g_batch", "kgh_ec_add", "kgh_parse_pubkey", "kgh_create_jump_table", "kgh_rng_new",
-    "kgh_rng_free", "kgh_rng_next", "kgh_create_herd", "kgh_synthetic_herd", "kgh_solver_new", "kgh_solver_free",
+    "kgh_rng_free", "kgh_rng_next", "kgh_create_herd", "kgh_herd_distances", "kgh_comb_table", "kgh_synthetic_herd", "kgh_solver_new", "kgh_solver_free",
     "kgh_solver_range_power", "kgh_solver_wild_offset", "kgh_solver_range_width", "kgh_solver_search_key",
     "kgh_solver_add", "kgh_solver_add_items", "kgh_solver_found", "kgh_solver_table_size", "kgh_solver_dead_count",
     "kgh_solver_dump",
@@ -33,6 +33,8 @@ def _lib():
             "kgh_rng_free": ([V], None),
             "kgh_rng_next": ([V], C.c_uint32),
             "kgh_create_herd": ([V, C.c_int, _u64p, _u64p, _u64p, C.c_int, C.c_size_t, _u64p, _u64p, _u64p], C.c_int),
+            "kgh_herd_distances": ([V, C.c_int, _u64p, C.c_int, C.c_size_t, _u64p], C.c_int),
+            "kgh_comb_table": ([C.POINTER(C.c_uint32), _u64p, _u64p], C.c_int),
             "kgh_synthetic_herd": ([_u64p, _u64p, C.c_size_t, _u64p, _u64p, _u64p], C.c_int),
             "kgh_solver_new": ([_u64p, _u64p, _u64p, _u64p], V),
             "kgh_solver_free": ([V], None),
@@ -123,6 +125,14 @@ def create_herd(rng, range_power, range_width, key, n, first_type=0):
     if rc:
         raise RuntimeError("kgh_create_herd failed")
     return px, py, d
+
+
+def herd_distances(rng, range_power, range_width, n, first_type=0):
+    d = np.zeros((n, 4), np.uint64)
+    rc = _lib().kgh_herd_distances(rng._h, range_power, _p(limbs(range_width)), first_type, n, _p(d))
+    if rc:
+        raise RuntimeError("kgh_herd_distances failed")
+    return d
 
 
 def synthetic_herd(n, d0=0x1234567, stride=0x9E3779B97F4A7C15F39CC0605CEDC835):

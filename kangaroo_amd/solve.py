@@ -39,14 +39,16 @@ def solve_key(range_start, range_end, pub, grid=(0, 0), gpu_id=0, dp_bits=None, 
         if dp_bits is None:
             dp_bits = suggested_dp(sv.range_power, n)
         rng = host.Rng(seed)
-        px, py, d = host.create_herd(rng, sv.range_power, sv.range_width, sv.key, n, 0)
+        # CreateHerd (core/kangaroo.cpp:521-573): the distances with the reference's RNG draws on the host,
+        # the points d*G (+ key for wild) on the GPU (kg_herd_from_distances)
+        d = host.herd_distances(rng, sv.range_power, sv.range_width, n, 0)
         jd, jx, jy, _ = host.create_jump_table(sv.range_power)
         eng.SetWildOffset(sv.wild_offset)
         eng.SetParams(dp_mask_of(dp_bits), jd, jx, jy)
         if nb_run:
             eng.SetNbRun(nb_run)
-        eng.SetKangaroos(px, py, d)
-        del px, py, d
+        eng.HerdFromDistances(d, sv.key)
+        del d
         steps = eng.nb_run
         t0 = time.perf_counter()
         eng.callKernel()
