@@ -77,6 +77,9 @@ int kgh_solver_add(kgh_solver *s, const uint64_t x[4], const uint64_t d[4], uint
 /* Batch form: items laid out as kg_item (72 bytes).  dead[] receives the indices (into items) that
  * need a reset, *n_dead their count.  Returns 2 as soon as the key is found, else 0. */
 int kgh_solver_add_items(kgh_solver *s, const void *items, uint32_t n, uint32_t *dead, uint32_t *n_dead);
+/* Worker threads used for batches of 8192 items and more (0 = hardware concurrency, at most 16).  The table is
+ * cut into 256 shards by x, so several callers (one per GPU) may also add batches concurrently. */
+void kgh_solver_set_threads(kgh_solver *s, int threads);
 int kgh_solver_found(const kgh_solver *s, uint64_t priv[4]);
 uint64_t kgh_solver_table_size(const kgh_solver *s);
 uint64_t kgh_solver_dead_count(const kgh_solver *s);

@@ -319,8 +319,9 @@ extern "C" int kg_create(int gpu_id, int groups, int per_group, uint32_t max_fou
   e->threads = e->grid * WALK_BLOCK;
   e->cap = (u64)e->threads * e->K;
   // the caller's maxFound is a hint (core/kangaroo.cpp:408); never smaller than it, and large
-  // enough for one DP per kangaroo per launch up to 4M items so that low-DP runs do not drop items
-  e->max_found = std::max<u32>(max_found, (u32)std::min<u64>(e->n, 1u << 22));
+  // enough for two DPs per kangaroo per launch up to 4M items so that low-DP runs (one DP per kangaroo and
+  // launch at DP = 8) do not drop items
+  e->max_found = std::max<u32>(max_found, (u32)std::min<u64>(2 * e->n, 1u << 22));
   snprintf(e->name, sizeof e->name, "GPU #%d %s (%dx%d cores) Grid(%dx%d)", gpu_id,
            prop.name[0] ? prop.name : prop.gcnArchName,
            prop.multiProcessorCount, 64 * 4, groups, per_group);

@@ -9,8 +9,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <mutex>
+#include <thread>
 #include <random>
 #include <unordered_map>
 #include <vector>
@@ -591,16 +594,62 @@ struct Entry {
   U256 x, d;
 };
 
+// DP ingest: the reference keeps one table of sorted buckets behind one mutex and inserts the
+// DPs of all GPU threads one by one (memory/hashtable.cpp:192-212, core/kangaroo.cpp:473-490).  Here the table is
+// cut into NSHARD independent open-addressing tables selected by bits of x; a DP's fate depends only on earlier
+// DPs with the same x, and those live in the same shard, so shards can be filled concurrently — by the worker
+// threads of one large batch and by the threads of several GPUs — while the per-x order of arrival is kept.
+constexpr int NSHARD = 256;
+struct Shard {
+  std::mutex mu;
+  std::vector<Key128> keys;  // h stored +1 so that 0 marks an empty cell
+  std::vector<Entry> vals;
+  size_t used = 0;
+  void grow() {
+    const size_t ncap = keys.empty() ? 1024 : keys.size() * 2;
+    std::vector<Key128> nk(ncap, Key128{0, 0, 0});
+    std::vector<Entry> nv(ncap);
+    for (size_t i = 0; i < keys.size(); ++i)
+      if (keys[i].h) {
+        size_t j = Key128Hash()(keys[i]) & (ncap - 1);
+        while (nk[j].h) j = (j + 1) & (ncap - 1);
+        nk[j] = keys[i];
+        nv[j] = vals[i];
+      }
+    keys.swap(nk);
+    vals.swap(nv);
+  }
+  // returns the cell of key (tagged), inserting e if absent; *existed tells which
+  Entry *find_or_insert(const Key128 &tagged, const Entry &e, bool *existed) {
+    if ((used + 1) * 5 > keys.size() * 3) grow();
+    size_t j = Key128Hash()(tagged) & (keys.size() - 1);
+    while (keys[j].h) {
+      if (keys[j] == tagged) {
+        *existed = true;
+        return &vals[j];
+      }
+      j = (j + 1) & (keys.size() - 1);
+    }
+    keys[j] = tagged;
+    vals[j] = e;
+    ++used;
+    *existed = false;
+    return &vals[j];
+  }
+};
+
 struct kgh_solver {
   U256 range_start, range_end, width, width2;
   int range_power;
   Aff pub, key, key_neg;
-  std::unordered_map<Key128, Entry, Key128Hash> table;
-  std::mutex mu;
-  bool found = false;
+  Shard shard[NSHARD];
+  std::mutex mu;  // guards found / priv / check_key
+  std::atomic<bool> found{false};
   U256 priv;
-  u64 dead = 0;
+  std::atomic<u64> dead{0};
+  int threads = 0;  // worker threads for large batches (0: hardware concurrency, capped at 16)
 };
+static inline int shard_of(const Key128 &k) { return (int)((k.lo * 0x9E3779B97F4A7C15ULL) >> 56); }
 
 static void ht_convert(const U256 &x, const U256 &d, uint32_t type, Key128 &key, Entry &e) {
   // memory/hashtable.cpp:65-89
@@ -654,33 +703,51 @@ static bool check_key(kgh_solver *s, U256 d1, U256 d2, int t) {
   return true;
 }
 
-static int add_locked(kgh_solver *s, const U256 &x, const U256 &d, u64 k_idx) {
+// One DP into its shard.  Returns 1 = stored, 0 = duplicate / same herd (dead kangaroo), 3 = tame/wild
+// collision (the caller resolves it with resolve_collision: EC work stays outside the shard lock).
+static int shard_add(kgh_solver *s, const U256 &x, const U256 &d, u64 k_idx, U256 *other_d, uint32_t *other_type) {
   const uint32_t type = (uint32_t)(k_idx & 1);
   Key128 key;
   Entry e;
   ht_convert(x, d, type, key, e);
-  auto it = s->table.find(key);
-  if (it == s->table.end()) {
-    s->table.emplace(key, e);
-    return 1;
-  }
-  if (cmp(it->second.d, e.d) == 0) {  // ADD_DUPLICATE -> treated as a dead kangaroo
+  Shard &sh = s->shard[shard_of(key)];
+  Key128 tagged = key;
+  tagged.h += 1;
+  std::lock_guard<std::mutex> lock(sh.mu);
+  bool existed;
+  Entry *cell = sh.find_or_insert(tagged, e, &existed);
+  if (!existed) return 1;
+  if (cmp(cell->d, e.d) == 0) {  // ADD_DUPLICATE -> treated as a dead kangaroo
     s->dead++;
     return 0;
   }
   U256 d0;
   uint32_t t0;
-  calc_dist_and_type(it->second.d, d0, t0);
+  calc_dist_and_type(cell->d, d0, t0);
   if (t0 == type) {  // same herd
     s->dead++;
     return 0;
   }
+  *other_d = d0;
+  *other_type = t0;
+  return 3;
+}
+// CollisionCheck (core/kangaroo.cpp:183-256): returns 2 = key found, 0 = wrong collision (dead kangaroo)
+static int resolve_collision(kgh_solver *s, const U256 &d, const U256 &d0, uint32_t t0) {
+  std::lock_guard<std::mutex> lock(s->mu);
+  if (s->found) return 2;
   const U256 &td = (t0 == 0) ? d0 : d;
   const U256 &wd = (t0 == 0) ? d : d0;
   for (int t = 0; t < 4; ++t)
     if (check_key(s, td, wd, t)) return 2;
   s->dead++;  // "Unexpected wrong collision, reset kangaroo" (core/kangaroo.cpp:206-223)
   return 0;
+}
+static int add_one(kgh_solver *s, const U256 &x, const U256 &d, u64 k_idx) {
+  U256 d0;
+  uint32_t t0;
+  const int r = shard_add(s, x, d, k_idx, &d0, &t0);
+  return r == 3 ? resolve_collision(s, d, d0, t0) : r;
 }
 
 kgh_solver *kgh_solver_new(const uint64_t range_start[4], const uint64_t range_end[4], const uint64_t pub_x[4],
@@ -712,40 +779,133 @@ void kgh_solver_search_key(const kgh_solver *s, uint64_t x[4], uint64_t y[4]) {
   store(y, s->key.y);
 }
 int kgh_solver_add(kgh_solver *s, const uint64_t x[4], const uint64_t d[4], uint64_t k_idx) {
-  std::lock_guard<std::mutex> lock(s->mu);
   if (s->found) return 2;
-  return add_locked(s, load(x), load(d), k_idx);
+  return add_one(s, load(x), load(d), k_idx);
 }
+void kgh_solver_set_threads(kgh_solver *s, int threads) { s->threads = threads < 0 ? 0 : threads; }
+
+// Batches below this size are inserted in arrival order by the calling thread (exactly the reference's
+// sequence, including "stop at the DP that solves the key"); larger ones are spread over worker threads by
+// shard.  In the threaded path every DP of the batch is inserted even if one of them solves the key.
+constexpr uint32_t PAR_BATCH = 8192;
+
 int kgh_solver_add_items(kgh_solver *s, const void *items, uint32_t n, uint32_t *dead, uint32_t *n_dead) {
   const kg_item *it = (const kg_item *)items;
   uint32_t nd = 0;
-  int rc = 0;
-  std::lock_guard<std::mutex> lock(s->mu);  // one lock per batch, as core/kangaroo.cpp:473-476
-  for (uint32_t i = 0; i < n && !s->found; ++i) {
-    int r = add_locked(s, load(it[i].x), load(it[i].d), it[i].kIdx);
-    if (r == 0 && dead) dead[nd++] = i;
-    if (r == 2) rc = 2;
+  int nthreads = s->threads > 0 ? s->threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 16u);
+  if (nthreads < 1) nthreads = 1;
+  if (n < PAR_BATCH || nthreads == 1) {
+    for (uint32_t i = 0; i < n && !s->found; ++i) {
+      const int r = add_one(s, load(it[i].x), load(it[i].d), it[i].kIdx);
+      if (r == 0 && dead) dead[nd++] = i;
+    }
+    if (n_dead) *n_dead = nd;
+    return s->found ? 2 : 0;
   }
-  if (s->found) rc = 2;
+  // 1. bucket the item indices by shard, keeping arrival order inside each shard
+  std::vector<uint32_t> start(NSHARD + 1, 0), order(n);
+  std::vector<uint8_t> sid(n);
+  {
+    std::vector<std::thread> th;
+    const uint32_t per = (n + nthreads - 1) / nthreads;
+    std::vector<std::vector<uint32_t>> cnt(nthreads, std::vector<uint32_t>(NSHARD, 0));
+    for (int t = 0; t < nthreads; ++t)
+      th.emplace_back([&, t] {
+        const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
+        for (uint32_t i = lo; i < hi; ++i) {
+          Key128 k;
+          k.lo = it[i].x[0];
+          const int sh = shard_of(k);
+          sid[i] = (uint8_t)sh;
+          cnt[t][sh]++;
+        }
+      });
+    for (auto &x : th) x.join();
+    th.clear();
+    // offsets: shard-major, thread-minor (threads hold consecutive slices, so this is arrival order)
+    std::vector<std::vector<uint32_t>> off(nthreads, std::vector<uint32_t>(NSHARD, 0));
+    uint32_t run = 0;
+    for (int sh = 0; sh < NSHARD; ++sh) {
+      start[sh] = run;
+      for (int t = 0; t < nthreads; ++t) {
+        off[t][sh] = run;
+        run += cnt[t][sh];
+      }
+    }
+    start[NSHARD] = run;
+    for (int t = 0; t < nthreads; ++t)
+      th.emplace_back([&, t] {
+        const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
+        for (uint32_t i = lo; i < hi; ++i) order[off[t][sid[i]]++] = i;
+      });
+    for (auto &x : th) x.join();
+  }
+  // 2. shards in parallel; dead kangaroos and tame/wild collisions are recorded per worker
+  struct Coll {
+    uint32_t idx;
+    U256 d0;
+    uint32_t t0;
+  };
+  std::vector<std::vector<uint32_t>> wdead(nthreads);
+  std::vector<std::vector<Coll>> wcoll(nthreads);
+  std::atomic<int> next{0};
+  {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+      th.emplace_back([&, t] {
+        for (;;) {
+          const int sh = next.fetch_add(1);
+          if (sh >= NSHARD) break;
+          for (uint32_t q = start[sh]; q < start[sh + 1]; ++q) {
+            const uint32_t i = order[q];
+            U256 d0;
+            uint32_t t0;
+            const int r = shard_add(s, load(it[i].x), load(it[i].d), it[i].kIdx, &d0, &t0);
+            if (r == 0) wdead[t].push_back(i);
+            else if (r == 3) wcoll[t].push_back(Coll{i, d0, t0});
+          }
+        }
+      });
+    for (auto &x : th) x.join();
+  }
+  // 3. collisions between herds, in arrival order (EC arithmetic, rare)
+  std::vector<Coll> coll;
+  for (auto &v : wcoll) coll.insert(coll.end(), v.begin(), v.end());
+  std::sort(coll.begin(), coll.end(), [](const Coll &a, const Coll &b) { return a.idx < b.idx; });
+  std::vector<uint32_t> all_dead;
+  for (auto &v : wdead) all_dead.insert(all_dead.end(), v.begin(), v.end());
+  for (const Coll &c : coll) {
+    if (s->found) break;
+    if (resolve_collision(s, load(it[c.idx].d), c.d0, c.t0) == 0) all_dead.push_back(c.idx);
+  }
+  std::sort(all_dead.begin(), all_dead.end());
+  if (dead)
+    for (uint32_t i : all_dead) dead[nd++] = i;
   if (n_dead) *n_dead = nd;
-  return rc;
+  return s->found ? 2 : 0;
 }
 int kgh_solver_found(const kgh_solver *s, uint64_t priv[4]) {
   if (!s->found) return 0;
   if (priv) store(priv, s->priv);
   return 1;
 }
-uint64_t kgh_solver_table_size(const kgh_solver *s) { return s->table.size(); }
+uint64_t kgh_solver_table_size(const kgh_solver *s) {
+  uint64_t n = 0;
+  for (const Shard &sh : s->shard) n += sh.used;
+  return n;
+}
 uint64_t kgh_solver_dead_count(const kgh_solver *s) { return s->dead; }
 uint64_t kgh_solver_dump(const kgh_solver *s, uint64_t *out, uint64_t cap) {
   uint64_t n = 0;
-  for (const auto &kv : s->table) {
-    if (n >= cap) break;
-    out[9 * n] = kv.first.h;
-    memcpy(out + 9 * n + 1, kv.second.x.v, 32);
-    memcpy(out + 9 * n + 5, kv.second.d.v, 32);
-    ++n;
-  }
+  for (const Shard &sh : s->shard)
+    for (size_t i = 0; i < sh.keys.size(); ++i) {
+      if (!sh.keys[i].h) continue;
+      if (n >= cap) return n;
+      out[9 * n] = sh.keys[i].h - 1;
+      memcpy(out + 9 * n + 1, sh.vals[i].x.v, 32);
+      memcpy(out + 9 * n + 5, sh.vals[i].d.v, 32);
+      ++n;
+    }
   return n;
 }
 

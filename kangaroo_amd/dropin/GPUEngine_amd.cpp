@@ -143,7 +143,7 @@ bool GPUEngine::Launch(std::vector<ITEM> &hashFound, bool spinWait) {
   if (!resultReady) return false;
   static thread_local std::vector<kg_item> items;
   const uint64_t herd = kg_nb_kangaroo(handle_of(resultReady));
-  const uint32_t ring = (uint32_t)(herd < (1u << 22) ? herd : (1u << 22));  // the engine's own ring depth
+  const uint32_t ring = (uint32_t)(2 * herd < (1u << 22) ? 2 * herd : (1u << 22));  // the engine's own ring depth
   const uint32_t cap = maxFound > ring ? maxFound : ring;
   if (items.size() < cap) items.resize(cap);
   uint32_t n = 0, lost = 0;

@@ -129,7 +129,7 @@ class GPUEngine:
         _chk(self._L.kg_device_name(self._h, buf, 256))
         self.deviceName = buf.value.decode()
         self.nbKangaroo = int(self._L.kg_nb_kangaroo(self._h))
-        self._cap = max(int(maxFound), min(self.nbKangaroo, 1 << 22))
+        self._cap = max(int(maxFound), min(2 * self.nbKangaroo, 1 << 22))
         self._items = np.zeros(self._cap, dtype=ITEM_DTYPE)
         self.lost = 0
         self.nb_run = 256  # NB_RUN, constants.h:21

@@ -11,7 +11,7 @@ _ready = False
 
 HOST_SYMBOLS = [
     "kgh_ec_mul_g", "kgh_ec_mul_g_batch", "kgh_ec_add", "kgh_parse_pubkey", "kgh_create_jump_table", "kgh_rng_new",
-    "kgh_rng_free", "kgh_rng_next", "kgh_create_herd", "kgh_herd_distances", "kgh_comb_table", "kgh_synthetic_herd", "kgh_solver_new", "kgh_solver_free",
+    "kgh_rng_free", "kgh_rng_next", "kgh_create_herd", "kgh_herd_distances", "kgh_comb_table", "kgh_synthetic_herd", "kgh_solver_new", "kgh_solver_free", "kgh_solver_set_threads",
     "kgh_solver_range_power", "kgh_solver_wild_offset", "kgh_solver_range_width", "kgh_solver_search_key",
     "kgh_solver_add", "kgh_solver_add_items", "kgh_solver_found", "kgh_solver_table_size", "kgh_solver_dead_count",
     "kgh_solver_dump",
@@ -35,6 +35,7 @@ def _lib():
             "kgh_create_herd": ([V, C.c_int, _u64p, _u64p, _u64p, C.c_int, C.c_size_t, _u64p, _u64p, _u64p], C.c_int),
             "kgh_herd_distances": ([V, C.c_int, _u64p, C.c_int, C.c_size_t, _u64p], C.c_int),
             "kgh_comb_table": ([C.POINTER(C.c_uint32), _u64p, _u64p], C.c_int),
+            "kgh_solver_set_threads": ([V, C.c_int], None),
             "kgh_synthetic_herd": ([_u64p, _u64p, C.c_size_t, _u64p, _u64p, _u64p], C.c_int),
             "kgh_solver_new": ([_u64p, _u64p, _u64p, _u64p], V),
             "kgh_solver_free": ([V], None),
@@ -156,6 +157,9 @@ class Solver:
         x, y = np.zeros(4, np.uint64), np.zeros(4, np.uint64)
         L.kgh_solver_search_key(self._h, _p(x), _p(y))
         self.key = (to_int(x), to_int(y))
+
+    def set_threads(self, threads):
+        _lib().kgh_solver_set_threads(self._h, threads)
 
     def add(self, x, d, k_idx):
         return _lib().kgh_solver_add(self._h, _p(limbs(x)), _p(limbs(d)), k_idx)

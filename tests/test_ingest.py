@@ -1,0 +1,62 @@
+"""DP ingest: the sharded, threaded batch insert must leave exactly the table, the dead-kangaroo list
+and the solution that inserting the same DPs one by one in arrival order leaves (the reference's order,
+core/kangaroo.cpp:473-490)."""
+import numpy as np
+
+import kgoracle as K
+from kangaroo_amd import host
+from kangaroo_amd.engine import ITEM_DTYPE
+
+
+def _items(n, seed, dup_every=7, same_herd_every=11):
+    """Random DPs with planted duplicates and same-herd collisions (never a tame/wild collision)."""
+    rnd = np.random.default_rng(seed)
+    it = np.zeros(n, dtype=ITEM_DTYPE)
+    it["x"] = rnd.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    it["d"] = rnd.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    it["d"][:, 2:] = 0
+    it["kIdx"] = rnd.integers(0, 1 << 20, size=n, dtype=np.uint64)
+    for i in range(dup_every, n, dup_every):        # exact duplicate of an earlier item
+        it[i] = it[i - dup_every]
+    for i in range(same_herd_every, n, same_herd_every):  # same x, same herd, other distance
+        j = i - same_herd_every
+        it["x"][i] = it["x"][j]
+        it["kIdx"][i] = (it["kIdx"][j] & 1) | (int(it["kIdx"][i]) & ~1)
+    return it
+
+
+def test_threaded_batch_equals_arrival_order():
+    pub = K.ec_mul_g(0x1234567)
+    items = _items(50000, 3)
+    a = host.Solver(0, (1 << 64) - 1, pub)
+    a.set_threads(1)
+    rc_a, dead_a = a.add_items(items)
+    b = host.Solver(0, (1 << 64) - 1, pub)
+    b.set_threads(6)
+    rc_b, dead_b = b.add_items(items)
+    c = host.Solver(0, (1 << 64) - 1, pub)
+    for it in items:  # one by one
+        c.add(host.to_int(it["x"]), host.to_int(it["d"]), int(it["kIdx"]))
+    assert rc_a == rc_b == 0
+    assert len(dead_a) > 5000 and np.array_equal(dead_a, dead_b)
+    assert a.table_size == b.table_size == c.table_size
+    assert a.dead == b.dead == c.dead == len(dead_a)
+    assert a.dump() == b.dump() == c.dump()
+
+
+def test_threaded_batch_finds_planted_key():
+    """A tame and a wild DP with the same x and distances that add up to the key, buried in a large batch."""
+    priv = 0xA5B3C1D2E7
+    pub = K.ec_mul_g(priv)
+    sv = host.Solver(0, (1 << 40) - 1, pub)
+    sv.set_threads(4)
+    items = _items(20000, 9)
+    td = 0x3141592653
+    wd = (td - priv) % K.N      # tame at td*G, wild at key + wd*G: same point when td = priv + wd
+    x = K.ec_mul_g(td)[0]
+    for pos, d, kidx in ((5000, td, 100), (15000, wd, 101)):
+        items["x"][pos] = [(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+        items["d"][pos] = [(d >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+        items["kIdx"][pos] = kidx
+    rc, _ = sv.add_items(items)
+    assert rc == 2 and sv.found == priv
