@@ -87,6 +87,18 @@ uint64_t kgh_solver_dead_count(const kgh_solver *s);
  * (memory/hashtable.cpp:65-89); returns the number written (<= cap). */
 uint64_t kgh_solver_dump(const kgh_solver *s, uint64_t *out, uint64_t cap);
 
+/* ---- work file, the reference's HEADW layout (storage/backup.cpp:256-428, memory/hashtable.cpp:262-324) ---- */
+/* Kangaroo::SaveWork: header, the DP table, and (if px/py/d are given) the kangaroos.  0 on success. */
+int kgh_work_save(const kgh_solver *s, const char *path, uint32_t dp_size, uint64_t total_count, double total_time,
+                  const uint64_t *px, const uint64_t *py, const uint64_t *d, uint64_t n_kangaroo);
+/* Kangaroo::WorkInfo (storage/backup.cpp:430-...): header fields and item counts without loading. */
+int kgh_work_info(const char *path, uint32_t *dp_size, uint64_t range_start[4], uint64_t range_end[4], uint64_t key_x[4],
+                  uint64_t key_y[4], uint64_t *total_count, double *total_time, uint64_t *n_items, uint64_t *n_kangaroo);
+/* Kangaroo::LoadWork + FetchWalks (storage/backup.cpp:54-253): the table into s, up to cap kangaroos into px/py/d.
+ * -5 if the file belongs to another range or key. */
+int kgh_work_load(kgh_solver *s, const char *path, uint64_t *px, uint64_t *py, uint64_t *d, uint64_t cap,
+                  uint64_t *n_loaded);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@
 // (memory/hashtable.cpp:65-226, core/kangaroo.cpp:155-256) — written from scratch on
 // 4x64-bit limbs with unsigned __int128, always fully reduced.
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -907,6 +908,149 @@ uint64_t kgh_solver_dump(const kgh_solver *s, uint64_t *out, uint64_t cap) {
       ++n;
     }
   return n;
+}
+
+
+// ---- work file ---------------------------------------------------------------------------------
+// Layout of the reference's "full work file" (HEADW), all little endian:
+//   u32 0xFA6A8001 (constants.h:43), u32 version 0                       storage/backup.cpp:256-271
+//   u32 dpSize, rangeStart[32], rangeEnd[32], key.x[32], key.y[32], u64 totalCount, f64 totalTime
+//                                                                         kangaroo.h:263-287, backup.cpp:273-286
+//   for each of the 2^18 buckets h: u32 nbItem, u32 maxItem, nbItem x { x[16], d[16] }
+//       (memory/hashtable.cpp:13-21,262-285), items ascending by (x.i64[1], x.i64[0]) (hashtable.cpp:192-226)
+//   u64 totalWalk, then totalWalk x { px[32], py[32], d[32] }           storage/backup.cpp:389-410
+// maxItem is the capacity of the reference's std::vector; a table filled by single inserts has the next power of
+// two, which is what is written here (any value >= nbItem loads).
+// PARITY UNPINNED for the file as a whole: no work file written by the reference is available as a fixture
+// (its tests hold none and binaries built from it are not run here); the entry packing itself (Convert) is
+// pinned by the reference DP tables in tests/golden/reference_vectors.json.
+namespace {
+constexpr uint32_t HEADW_MAGIC = 0xFA6A8001u;
+constexpr uint32_t HASH_BUCKETS = 1u << 18;
+struct FileEntry {
+  u64 x[2], d[2];
+};
+bool wr(FILE *f, const void *p, size_t n) { return fwrite(p, 1, n, f) == n; }
+bool rd(FILE *f, void *p, size_t n) { return fread(p, 1, n, f) == n; }
+}  // namespace
+
+int kgh_work_save(const kgh_solver *s, const char *path, uint32_t dp_size, uint64_t total_count, double total_time,
+                  const uint64_t *px, const uint64_t *py, const uint64_t *d, uint64_t n_kangaroo) {
+  if (!s || !path) return -1;
+  FILE *f = fopen(path, "wb");
+  if (!f) return -2;
+  const uint32_t version = 0;
+  bool ok = wr(f, &HEADW_MAGIC, 4) && wr(f, &version, 4) && wr(f, &dp_size, 4) && wr(f, s->range_start.v, 32) &&
+            wr(f, s->range_end.v, 32) && wr(f, s->pub.x.v, 32) && wr(f, s->pub.y.v, 32) && wr(f, &total_count, 8) &&
+            wr(f, &total_time, 8);
+  // gather the shards into the reference's 2^18 buckets
+  std::vector<uint32_t> cnt(HASH_BUCKETS + 1, 0);
+  for (const Shard &sh : s->shard)
+    for (size_t i = 0; i < sh.keys.size(); ++i)
+      if (sh.keys[i].h) cnt[sh.keys[i].h - 1 + 1]++;
+  for (uint32_t h = 0; h < HASH_BUCKETS; ++h) cnt[h + 1] += cnt[h];
+  std::vector<FileEntry> all(cnt[HASH_BUCKETS]);
+  {
+    std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
+    for (const Shard &sh : s->shard)
+      for (size_t i = 0; i < sh.keys.size(); ++i)
+        if (sh.keys[i].h) {
+          FileEntry &e = all[pos[sh.keys[i].h - 1]++];
+          e.x[0] = sh.vals[i].x.v[0];
+          e.x[1] = sh.vals[i].x.v[1];
+          e.d[0] = sh.vals[i].d.v[0];
+          e.d[1] = sh.vals[i].d.v[1];
+        }
+  }
+  for (uint32_t h = 0; h < HASH_BUCKETS && ok; ++h) {
+    FileEntry *b = all.data() + cnt[h];
+    const uint32_t nb = cnt[h + 1] - cnt[h];
+    std::sort(b, b + nb, [](const FileEntry &l, const FileEntry &r) { return l.x[1] != r.x[1] ? l.x[1] < r.x[1] : l.x[0] < r.x[0]; });
+    uint32_t cap = 0;
+    if (nb) {
+      cap = 1;
+      while (cap < nb) cap <<= 1;
+    }
+    ok = wr(f, &nb, 4) && wr(f, &cap, 4) && (nb == 0 || wr(f, b, (size_t)nb * sizeof(FileEntry)));
+  }
+  const uint64_t walks = (px && py && d) ? n_kangaroo : 0;
+  ok = ok && wr(f, &walks, 8);
+  for (uint64_t i = 0; i < walks && ok; ++i) ok = wr(f, px + 4 * i, 32) && wr(f, py + 4 * i, 32) && wr(f, d + 4 * i, 32);
+  ok = (fclose(f) == 0) && ok;
+  return ok ? 0 : -3;
+}
+
+int kgh_work_info(const char *path, uint32_t *dp_size, uint64_t range_start[4], uint64_t range_end[4], uint64_t key_x[4],
+                  uint64_t key_y[4], uint64_t *total_count, double *total_time, uint64_t *n_items, uint64_t *n_kangaroo) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return -2;
+  uint32_t magic = 0, version = 0, dp = 0;
+  u64 rs[4], re[4], kx[4], ky[4], tc = 0, items = 0, walks = 0;
+  double tt = 0;
+  bool ok = rd(f, &magic, 4) && rd(f, &version, 4) && magic == HEADW_MAGIC && rd(f, &dp, 4) && rd(f, rs, 32) && rd(f, re, 32) &&
+            rd(f, kx, 32) && rd(f, ky, 32) && rd(f, &tc, 8) && rd(f, &tt, 8);
+  for (uint32_t h = 0; h < HASH_BUCKETS && ok; ++h) {  // HashTable::SeekNbItem, memory/hashtable.cpp:296-306
+    uint32_t nb, cap;
+    ok = rd(f, &nb, 4) && rd(f, &cap, 4) && fseeko(f, (off_t)nb * 32, SEEK_CUR) == 0;
+    items += nb;
+  }
+  ok = ok && rd(f, &walks, 8);
+  fclose(f);
+  if (!ok) return -4;
+  if (dp_size) *dp_size = dp;
+  if (range_start) memcpy(range_start, rs, 32);
+  if (range_end) memcpy(range_end, re, 32);
+  if (key_x) memcpy(key_x, kx, 32);
+  if (key_y) memcpy(key_y, ky, 32);
+  if (total_count) *total_count = tc;
+  if (total_time) *total_time = tt;
+  if (n_items) *n_items = items;
+  if (n_kangaroo) *n_kangaroo = walks;
+  return 0;
+}
+
+// Loads the table of a work file into s (which must have been created for the same range and key: checked) and
+// up to cap kangaroos into px/py/d.  Kangaroo::LoadWork + FetchWalks (storage/backup.cpp:54-253).
+int kgh_work_load(kgh_solver *s, const char *path, uint64_t *px, uint64_t *py, uint64_t *d, uint64_t cap,
+                  uint64_t *n_loaded) {
+  if (!s || !path) return -1;
+  FILE *f = fopen(path, "rb");
+  if (!f) return -2;
+  uint32_t magic = 0, version = 0, dp = 0;
+  u64 rs[4], re[4], kx[4], ky[4], tc = 0, walks = 0;
+  double tt = 0;
+  bool ok = rd(f, &magic, 4) && rd(f, &version, 4) && magic == HEADW_MAGIC && rd(f, &dp, 4) && rd(f, rs, 32) && rd(f, re, 32) &&
+            rd(f, kx, 32) && rd(f, ky, 32) && rd(f, &tc, 8) && rd(f, &tt, 8);
+  if (ok && (memcmp(rs, s->range_start.v, 32) || memcmp(re, s->range_end.v, 32) || memcmp(kx, s->pub.x.v, 32) ||
+             memcmp(ky, s->pub.y.v, 32))) {
+    fclose(f);
+    return -5;  // another range or key
+  }
+  std::vector<FileEntry> buf;
+  for (uint32_t h = 0; h < HASH_BUCKETS && ok; ++h) {
+    uint32_t nb, capb;
+    ok = rd(f, &nb, 4) && rd(f, &capb, 4);
+    if (!ok || !nb) continue;
+    buf.resize(nb);
+    ok = rd(f, buf.data(), (size_t)nb * sizeof(FileEntry));
+    for (uint32_t i = 0; i < nb && ok; ++i) {
+      Key128 key{(u64)h + 1, buf[i].x[0], buf[i].x[1]};
+      Entry e;
+      e.x = U256{{buf[i].x[0], buf[i].x[1], 0, 0}};
+      e.d = U256{{buf[i].d[0], buf[i].d[1], 0, 0}};
+      Shard &sh = s->shard[shard_of(key)];
+      std::lock_guard<std::mutex> lock(sh.mu);
+      bool existed;
+      sh.find_or_insert(key, e, &existed);
+    }
+  }
+  ok = ok && rd(f, &walks, 8);
+  uint64_t got = 0;
+  for (; ok && got < walks && got < cap && px && py && d; ++got)
+    ok = rd(f, px + 4 * got, 32) && rd(f, py + 4 * got, 32) && rd(f, d + 4 * got, 32);
+  fclose(f);
+  if (n_loaded) *n_loaded = got;
+  return ok ? 0 : -4;
 }
 
 }  // extern "C"

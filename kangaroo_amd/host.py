@@ -11,7 +11,7 @@ _ready = False
 
 HOST_SYMBOLS = [
     "kgh_ec_mul_g", "kgh_ec_mul_g_batch", "kgh_ec_add", "kgh_parse_pubkey", "kgh_create_jump_table", "kgh_rng_new",
-    "kgh_rng_free", "kgh_rng_next", "kgh_create_herd", "kgh_herd_distances", "kgh_comb_table", "kgh_synthetic_herd", "kgh_solver_new", "kgh_solver_free", "kgh_solver_set_threads",
+    "kgh_rng_free", "kgh_rng_next", "kgh_create_herd", "kgh_herd_distances", "kgh_comb_table", "kgh_synthetic_herd", "kgh_solver_new", "kgh_solver_free", "kgh_solver_set_threads", "kgh_work_save", "kgh_work_info", "kgh_work_load",
     "kgh_solver_range_power", "kgh_solver_wild_offset", "kgh_solver_range_width", "kgh_solver_search_key",
     "kgh_solver_add", "kgh_solver_add_items", "kgh_solver_found", "kgh_solver_table_size", "kgh_solver_dead_count",
     "kgh_solver_dump",
@@ -36,6 +36,10 @@ def _lib():
             "kgh_herd_distances": ([V, C.c_int, _u64p, C.c_int, C.c_size_t, _u64p], C.c_int),
             "kgh_comb_table": ([C.POINTER(C.c_uint32), _u64p, _u64p], C.c_int),
             "kgh_solver_set_threads": ([V, C.c_int], None),
+            "kgh_work_save": ([V, C.c_char_p, C.c_uint32, C.c_uint64, C.c_double, _u64p, _u64p, _u64p, C.c_uint64], C.c_int),
+            "kgh_work_info": ([C.c_char_p, C.POINTER(C.c_uint32), _u64p, _u64p, _u64p, _u64p, C.POINTER(C.c_uint64),
+                               C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)], C.c_int),
+            "kgh_work_load": ([V, C.c_char_p, _u64p, _u64p, _u64p, C.c_uint64, C.POINTER(C.c_uint64)], C.c_int),
             "kgh_synthetic_herd": ([_u64p, _u64p, C.c_size_t, _u64p, _u64p, _u64p], C.c_int),
             "kgh_solver_new": ([_u64p, _u64p, _u64p, _u64p], V),
             "kgh_solver_free": ([V], None),
@@ -142,6 +146,18 @@ def synthetic_herd(n, d0=0x1234567, stride=0x9E3779B97F4A7C15F39CC0605CEDC835):
     return px, py, d
 
 
+def work_info(path):
+    """Kangaroo::WorkInfo: header of a work file."""
+    dp, tc, tt, ni, nk = C.c_uint32(0), C.c_uint64(0), C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+    rs, re, kx, ky = (np.zeros(4, np.uint64) for _ in range(4))
+    rc = _lib().kgh_work_info(path.encode(), C.byref(dp), _p(rs), _p(re), _p(kx), _p(ky), C.byref(tc), C.byref(tt),
+                              C.byref(ni), C.byref(nk))
+    if rc:
+        raise RuntimeError(f"kgh_work_info failed ({rc})")
+    return {"dp_bits": dp.value, "range_start": to_int(rs), "range_end": to_int(re), "key": (to_int(kx), to_int(ky)),
+            "total_count": tc.value, "total_time": tt.value, "items": ni.value, "kangaroos": nk.value}
+
+
 class Solver:
     """DP table + collision resolution (HashTable / AddToTable / CollisionCheck / CheckKey)."""
 
@@ -186,6 +202,25 @@ class Solver:
     @property
     def dead(self):
         return int(_lib().kgh_solver_dead_count(self._h))
+
+    def save_work(self, path, dp_bits, total_count=0, total_time=0.0, herd=None):
+        """Kangaroo::SaveWork: header + DP table (+ kangaroos if herd = (px, py, d) is given)."""
+        if herd is None:
+            rc = _lib().kgh_work_save(self._h, path.encode(), dp_bits, total_count, total_time, None, None, None, 0)
+        else:
+            px, py, d = (np.ascontiguousarray(a, dtype=np.uint64) for a in herd)
+            rc = _lib().kgh_work_save(self._h, path.encode(), dp_bits, total_count, total_time, _p(px), _p(py), _p(d), len(px))
+        if rc:
+            raise RuntimeError(f"kgh_work_save failed ({rc})")
+
+    def load_work(self, path, max_kangaroos=0):
+        """Kangaroo::LoadWork: table into this solver; returns (px, py, d) of the saved kangaroos (up to max)."""
+        px, py, d = (np.zeros((max(max_kangaroos, 1), 4), np.uint64) for _ in range(3))
+        got = C.c_uint64(0)
+        rc = _lib().kgh_work_load(self._h, path.encode(), _p(px), _p(py), _p(d), max_kangaroos, C.byref(got))
+        if rc:
+            raise RuntimeError(f"kgh_work_load failed ({rc})")
+        return px[: got.value], py[: got.value], d[: got.value]
 
     def dump(self):
         n = self.table_size
