@@ -153,8 +153,9 @@ def main():
     # register-resident kernels only load/store the herd once per launch.
     name = eng.KernelName()
     if "stream" in name:
-        groups = (27 + info["delta_words"] + 2) // 3
-        bytes_per_jump = 2 * groups * 12 + STATE_BYTES_PER_KANGAROO / args.nb_run
+        # 9 groups of 12 B read and written, 1 B of jump-index history written, and per launch the herd
+        # planes (192 B) plus the history read back once by the epilogue (1 B per jump)
+        bytes_per_jump = 2 * 9 * 12 + 1 + 1 + STATE_BYTES_PER_KANGAROO / args.nb_run
     else:
         bytes_per_jump = STATE_BYTES_PER_KANGAROO / args.nb_run
     hbm_gbps = kernel_jumps_per_s * bytes_per_jump / 1e9

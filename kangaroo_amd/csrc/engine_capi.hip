@@ -632,7 +632,8 @@ extern "C" int kg_kick(kg_engine *e) {
   const StreamVariant *sv = e->streaming ? find_stream_variant(e->DW) : nullptr;
   if (!v && !sv) return fail(KG_ERR_STATE, "GPUEngine: Kernel: no kernel variant for this configuration");
   if (sv) {
-    const size_t need = (size_t)ws_groups(e->DW) * 3 * (size_t)e->K * (size_t)e->threads * sizeof(u32);
+    const size_t ws_part = (size_t)WS_GROUPS * 3 * (size_t)e->K * (size_t)e->threads * sizeof(u32);
+    const size_t need = ws_part + (size_t)e->nb_run * (size_t)e->K * (size_t)e->threads;  // + jump-index history
     if (need > e->ws_bytes) {
       HIPCHK(hipStreamSynchronize(e->stream));
       if (e->ws) (void)hipFree(e->ws);
@@ -666,6 +667,7 @@ extern "C" int kg_kick(kg_engine *e) {
     StreamArgs sa;
     sa.a = a;
     sa.ws = e->ws;
+    sa.hist = (unsigned char *)e->ws + (size_t)WS_GROUPS * 3 * (size_t)e->K * (size_t)e->threads * sizeof(u32);
     sa.K = (u32)e->K;
     hipLaunchKernelGGL(sv->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, sa);
   } else {

@@ -7,13 +7,15 @@
 // more waves per SIMD than with one.  Here a lane owns K kangaroos with K set at run time (64 for the
 // bench herd), the inverse is amortised over K, registers hold one body's working set, so 2-3 waves per
 // SIMD fit, and the code is one rolled body (~12 KB, instruction-cache resident).  The price is HBM
-// traffic: 4 * (2 * (18 + DW) + 2 * 9) bytes per jump (240 B for DW = 3), all of it lane-contiguous
-// dword rows.
+// traffic: 2 * 9 * 12 + 1 = 217 bytes per jump, all of it lane-contiguous rows.
 //
-// Workspace (engine-private, HBM): a kangaroo slot is R = 27 + DW words per lane
-//   words 0..8 x limbs, 9..17 y limbs, 18..18+DW-1 delta words, then the 9 limbs of the stored partial product P[k],
-// cut into G = ceil(R / 3) groups of three words; group g of slot k is a row of `threads` 12-byte entries at
-// row index k * G + g, so that one buffer_load/store_dwordx3 moves 768 contiguous bytes per wavefront.  The prologue converts X/Y planes into the workspace, the epilogue converts back and
+// Workspace (engine-private, HBM): a kangaroo slot is 27 words per lane
+//   words 0..8 x limbs, 9..17 y limbs, 18..26 the 9 limbs of the stored partial product P[k],
+// cut into 9 groups of three words; group g of slot k is a row of `threads` 12-byte entries at row index
+// k * 9 + g, so that one buffer_load/store_dwordx3 moves 768 contiguous bytes per wavefront.
+// Distances are not carried through the steps at all: every jump appends its jump index (one byte) to a
+// history hist[step][slot][lane]; the distance travelled is summed from the history by the epilogue, and by the
+// few lanes that report a distinguished point.  1 byte per jump instead of reading and writing the delta.  The prologue converts X/Y planes into the workspace, the epilogue converts back and
 // adds the deltas to D, so the engine's resident format (walk_kernel.h) is unchanged.
 //
 // The step itself is the fused pass of walk_kernel_rot.h: same arithmetic, same results.
@@ -24,14 +26,13 @@ namespace kg {
 
 struct StreamArgs {
   WalkArgs a;
-  u32 *ws;  // workspace, R * K rows of a.threads u32
-  u32 K;    // kangaroos per lane
+  u32 *ws;            // workspace, 9 * K rows of a.threads 12-byte entries
+  unsigned char *hist;  // jump indices, [nb_run][K][a.threads]
+  u32 K;              // kangaroos per lane
 };
 
-template <int DW>
 struct StreamRec {
   fe x, y;
-  dlt<DW> dl;
 };
 
 // Workspace access: one buffer descriptor per kangaroo slot (base = first row of the slot, range = the slot's
@@ -39,7 +40,7 @@ struct StreamRec {
 // uniform SGPR offset and the lane as a constant VGPR byte offset: no per-access address arithmetic on the VALU.
 typedef __amdgpu_buffer_rsrc_t ws_rsrc;
 typedef u32 u32x3 __attribute__((ext_vector_type(3)));
-constexpr u32 ws_groups(int DW) { return (27 + DW + 2) / 3; }
+constexpr u32 WS_GROUPS = 9;
 __device__ __forceinline__ ws_rsrc ws_slot(u32 *ws, u32 threads, u32 groups, u32 id) {
   return __builtin_amdgcn_make_buffer_rsrc(ws + (u64)id * groups * 3u * threads, 0, (int)(groups * threads * 12u), 0x00020000);
 }
@@ -90,42 +91,60 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   const u32 K = sa.K;
   const u32 threads = a.threads;
   u32 *ws = sa.ws;
-  constexpr u32 G = ws_groups(DW);
+  constexpr u32 G = WS_GROUPS;
   const u32 rowb = threads * 12u;  // bytes per workspace row
 
-  auto load_rec = [&](StreamRec<DW> &r, u32 id) {
+  auto load_rec = [&](StreamRec &r, u32 id) {
     const ws_rsrc rs = ws_slot(ws, threads, G, id);
-    u32 wv[18 + DW];
-    ws_load<0, 18 + DW>(wv, rs, off, rowb);
+    u32 wv[18];
+    ws_load<0, 18>(wv, rs, off, rowb);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
       r.x.l[i] = wv[i];
       r.y.l[i] = wv[9 + i];
     }
-#pragma unroll
-    for (int i = 0; i < DW; ++i) r.dl.w[i] = wv[18 + i];
   };
   auto load_p = [&](fe &q, u32 id) {
     const ws_rsrc rs = ws_slot(ws, threads, G, id);
-    ws_load<18 + DW, 9>(q.l, rs, off, rowb);
+    ws_load<18, 9>(q.l, rs, off, rowb);
   };
-  auto store_all = [&](u32 id, const fe &x, const fe &y, const dlt<DW> &dl, const fe &pp) {
+  auto store_all = [&](u32 id, const fe &x, const fe &y, const fe &pp) {
     const ws_rsrc rs = ws_slot(ws, threads, G, id);
-    u32 wv[3 * G];
+    u32 wv[27];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
       wv[i] = x.l[i];
       wv[9 + i] = y.l[i];
-      wv[18 + DW + i] = pp.l[i];
+      wv[18 + i] = pp.l[i];
     }
-#pragma unroll
-    for (int i = 0; i < DW; ++i) wv[18 + i] = dl.w[i];
-#pragma unroll
-    for (int i = 27 + DW; i < (int)(3 * G); ++i) wv[i] = 0u;
+#ifdef KG_EXP_NO_XY  // timing experiment only (results wrong)
+    ws_store<6, G - 1>(rs, off, rowb, wv + 18);
+#else
     ws_store<0, G - 1>(rs, off, rowb, wv);
+#endif
+  };
+  // history row of (step, slot): K * threads bytes per step
+  auto hist_row = [&](u32 step, u32 id) { return sa.hist + ((u64)step * K + id) * threads; };
+  // distance travelled by slot id in steps [0, steps): sum of the jump distances in its history
+  auto travelled = [&](dlt<DW> &sum, u32 steps, u32 id) {
+#pragma unroll
+    for (int i = 0; i < DW; ++i) sum.w[i] = 0u;
+    constexpr u32 CH = 32;  // history bytes requested together, so that their latencies overlap
+#pragma unroll 1
+    for (u32 r0 = 0; r0 < steps; r0 += CH) {
+      u32 j[CH];
+#pragma unroll
+      for (u32 i = 0; i < CH; ++i) {
+        const u32 r = r0 + i < steps ? r0 + i : r0;  // clamped: a valid row, masked out below
+        j[i] = hist_row(r, id)[Tl];
+      }
+#pragma unroll
+      for (u32 i = 0; i < CH; ++i)
+        if (r0 + i < steps) delta_add<DW>(sum.w, jdist + j[i] * DW);
+    }
   };
 
-  // ---- prologue: X/Y planes -> workspace, zero deltas, prefix products of the first step's dx (ascending) ----
+  // ---- prologue: X/Y planes -> workspace, prefix products of the first step's dx (ascending) ----
   fe acc;
 #pragma unroll
   for (int i = 0; i < 9; ++i) acc.l[i] = (i == 0);
@@ -154,10 +173,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     for (int i = 0; i < 9; ++i) jx.l[i] = row[i];
     fe_sub_wide(dx, x, jx);
     fe_mul(acc, dx, acc);
-    dlt<DW> zero;
-#pragma unroll
-    for (int i = 0; i < DW; ++i) zero.w[i] = 0u;
-    store_all(k, x, y, zero, acc);
+    store_all(k, x, y, acc);
   }
 
   // ---- steps: pass `run` visits the ids descending when run is even (the prologue went up), ascending when odd ----
@@ -167,7 +183,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     const bool asc = (run & 1) != 0;
     const int dir = asc ? 1 : -1;
     // operands of the first kangaroo of the pass: requested before the inversion, which hides the latency
-    StreamRec<DW> cur;
+    StreamRec cur;
     fe cur_q;
     {
       const u32 id0 = asc ? 0u : K - 1;
@@ -184,7 +200,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     for (u32 t = 0; t < K; ++t) {
       const u32 id = asc ? t : K - 1 - t;
       // prefetch the next kangaroo (clamped at the end of the pass: loads a valid slot that is not used)
-      StreamRec<DW> nxt;
+      StreamRec nxt;
       fe nxt_q;
       {
         const u32 tn = t + 1 < K ? t + 1 : t;
@@ -223,7 +239,9 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       fe_mul(ry, tt, s);
       fe_sub_wide(ry, ry, cur.y);
       fe_weak(ry);
-      delta_add<DW>(cur.dl.w, jdist + jmp * DW);
+#ifndef KG_EXP_NO_HIST  // timing experiment only (results wrong)
+      hist_row(run, id)[Tl] = (unsigned char)jmp;
+#endif
 
       // next step's dx and running product
       {
@@ -234,7 +252,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
         fe_sub_wide(dx2, rx, jx2);
         fe_mul(acc, dx2, acc);
       }
-      store_all(id, rx, ry, cur.dl, acc);
+      store_all(id, rx, ry, acc);
 
       // distinguished point: (x.bits64[3] & dpMask) == 0   (math/gpu/compute.h:54)
       const u32 top_hi = (rx.l[8] << 8) | (rx.l[7] >> 21);
@@ -256,7 +274,10 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
             fe_to_words(w, rx);
 #pragma unroll
             for (int i = 0; i < 8; ++i) it->x[i] = w[i];
-            add_dist_256<DW>(w, a.D, a.cap, p, cur.dl);
+            dlt<DW> dl;
+            travelled(dl, run, id);  // steps before this one, from the history (this branch is rare)
+            delta_add<DW>(dl.w, jdist + jmp * DW);
+            add_dist_256<DW>(w, a.D, a.cap, p, dl);
 #pragma unroll
             for (int i = 0; i < 8; ++i) it->d[i] = w[i];
             it->kidx = p;
@@ -268,10 +289,10 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     }
   } while (++run < a.nb_run);
 
-  // ---- epilogue: workspace -> X/Y planes (canonical), D += delta ----
+  // ---- epilogue: workspace -> X/Y planes (canonical), D += distance travelled ----
 #pragma unroll 1
   for (u32 k = 0; k < K; ++k) {
-    StreamRec<DW> r;
+    StreamRec r;
     load_rec(r, k);
     const u64 p = T + (u64)k * threads;
     u32 w[8];
@@ -283,7 +304,9 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     fe_to_words(w, r.y);
 #pragma unroll
     for (int i = 0; i < 4; ++i) a.Y[(u64)i * a.cap + p] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
-    add_dist_256<DW>(w, a.D, a.cap, p, r.dl);
+    dlt<DW> dl;
+    travelled(dl, a.nb_run, k);
+    add_dist_256<DW>(w, a.D, a.cap, p, dl);
 #pragma unroll
     for (int i = 0; i < 4; ++i) a.D[(u64)i * a.cap + p] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
   }
