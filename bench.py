@@ -153,9 +153,10 @@ def main():
     # register-resident kernels only load/store the herd once per launch.
     name = eng.KernelName()
     if "stream" in name:
-        # 9 groups of 12 B read and written, 1 B of jump-index history written, and per launch the herd
-        # planes (192 B) plus the history read back once by the epilogue (1 B per jump)
-        bytes_per_jump = 2 * 9 * 12 + 1 + 1 + STATE_BYTES_PER_KANGAROO / args.nb_run
+        # per jump: x, y read and written (72 + 72 B), one stored partial product per pair of kangaroos read and
+        # written (18 + 18 B), 1 B of jump-index history written and read back once by the epilogue; per
+        # launch the herd planes (192 B per kangaroo)
+        bytes_per_jump = 72 + 72 + 18 + 18 + 1 + 1 + STATE_BYTES_PER_KANGAROO / args.nb_run
     else:
         bytes_per_jump = STATE_BYTES_PER_KANGAROO / args.nb_run
     hbm_gbps = kernel_jumps_per_s * bytes_per_jump / 1e9

@@ -304,7 +304,8 @@ extern "C" int kg_create(int gpu_id, int groups, int per_group, uint32_t max_fou
     // K kangaroos per lane such that the herd fills about KG_W (2) waves per SIMD; KG_K overrides
     const u64 lanes = (u64)e->cus * 4 * 64 * (u64)env_int("KG_W", 2);
     u64 k = env_int("KG_K", 0) > 0 ? (u64)env_int("KG_K", 0) : (e->n + lanes - 1) / lanes;
-    e->K = (int)std::min<u64>(std::max<u64>(k, env_int("KG_K", 0) > 0 ? 1 : 4), 1024);
+    e->K = (int)std::min<u64>(std::max<u64>(k, env_int("KG_K", 0) > 0 ? 2 : 4), 1024);
+    e->K += e->K & 1;  // the streaming kernel handles kangaroos in pairs
   } else {
     e->K = default_k();
   }
@@ -633,6 +634,8 @@ extern "C" int kg_kick(kg_engine *e) {
   if (!v && !sv) return fail(KG_ERR_STATE, "GPUEngine: Kernel: no kernel variant for this configuration");
   if (sv) {
     const size_t ws_part = (size_t)WS_GROUPS * 3 * (size_t)e->K * (size_t)e->threads * sizeof(u32);
+    if (ws_part >= (1ull << 32))
+      return fail(KG_ERR_ARG, "GPUEngine: Kernel: herd too large for the streaming kernel's 4 GiB workspace (KG_MODE=reg lifts the limit)");
     const size_t need = ws_part + (size_t)e->nb_run * (size_t)e->K * (size_t)e->threads;  // + jump-index history
     if (need > e->ws_bytes) {
       HIPCHK(hipStreamSynchronize(e->stream));

@@ -7,7 +7,8 @@
 // more waves per SIMD than with one.  Here a lane owns K kangaroos with K set at run time (64 for the
 // bench herd), the inverse is amortised over K, registers hold one body's working set, so 2-3 waves per
 // SIMD fit, and the code is one rolled body (~12 KB, instruction-cache resident).  The price is HBM
-// traffic: 2 * 9 * 12 + 1 = 217 bytes per jump, all of it lane-contiguous rows.
+// traffic: 72 + 18 B read, 72 + 18 + 1 B written per jump (kangaroos go in pairs and share one stored partial
+// product), all of it lane-contiguous rows.
 //
 // Workspace (engine-private, HBM): a kangaroo slot is 27 words per lane
 //   words 0..8 x limbs, 9..17 y limbs, 18..26 the 9 limbs of the stored partial product P[k],
@@ -35,38 +36,47 @@ struct StreamRec {
   fe x, y;
 };
 
-// Workspace access: one buffer descriptor per kangaroo slot (base = first row of the slot, range = the slot's
-// R rows, so a wrong offset is dropped by the hardware bounds check instead of faulting), the row as a
-// uniform SGPR offset and the lane as a constant VGPR byte offset: no per-access address arithmetic on the VALU.
+// Workspace access through a buffer descriptor: an offset outside the workspace is dropped by the hardware
+// bounds check instead of faulting, and there is no per-access address arithmetic on the VALU.
 typedef __amdgpu_buffer_rsrc_t ws_rsrc;
 typedef u32 u32x3 __attribute__((ext_vector_type(3)));
 constexpr u32 WS_GROUPS = 9;
-__device__ __forceinline__ ws_rsrc ws_slot(u32 *ws, u32 threads, u32 groups, u32 id) {
-  return __builtin_amdgcn_make_buffer_rsrc(ws + (u64)id * groups * 3u * threads, 0, (int)(groups * threads * 12u), 0x00020000);
-}
-// words [FIRST, FIRST + N) of a slot -> dst[0..N)
+// One descriptor for the whole workspace (the host keeps it below 4 GiB); a group row is addressed by a
+// uniform SGPR offset (slot * 9 + group) * row_bytes, the lane by a constant VGPR byte offset.
+struct ws_ref {
+  ws_rsrc rs;
+  u32 row_bytes;  // threads * 12
+  u32 off;        // lane * 12
+};
+// words [FIRST, FIRST + N) of slot id -> dst[0..N)
 template <int FIRST, int N>
-__device__ __forceinline__ void ws_load(u32 *dst, ws_rsrc rs, u32 off_bytes, u32 row_bytes) {
+__device__ __forceinline__ void ws_load(u32 *dst, const ws_ref &w, u32 id) {
   constexpr int G0 = FIRST / 3, G1 = (FIRST + N - 1) / 3;
+  const u32 base = id * WS_GROUPS;
 #pragma unroll
   for (int g = G0; g <= G1; ++g) {
-    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, off_bytes, (u32)g * row_bytes, 0);
+    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(w.rs, w.off, (base + (u32)g) * w.row_bytes, 0);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const int w = 3 * g + c - FIRST;
-      if (w >= 0 && w < N) dst[w] = v[c];
+      const int i = 3 * g + c - FIRST;
+      if (i >= 0 && i < N) dst[i] = v[c];
     }
   }
 }
-// groups [G0, G1] of a slot <- src, where src[i] is word 3 * G0 + i of the slot
+// groups [G0, G1] of slot id <- src, where src[i] is word 3 * G0 + i of the slot
 template <int G0, int G1>
-__device__ __forceinline__ void ws_store(ws_rsrc rs, u32 off_bytes, u32 row_bytes, const u32 *src) {
+__device__ __forceinline__ void ws_store(const ws_ref &w, u32 id, const u32 *src) {
+  const u32 base = id * WS_GROUPS;
 #pragma unroll
   for (int g = G0; g <= G1; ++g) {
     u32x3 v;
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = src[3 * (g - G0) + c];
-    __builtin_amdgcn_raw_buffer_store_b96(v, rs, off_bytes, (u32)g * row_bytes, 0);
+#ifdef KG_EXP_STORE_SLOT0  // timing experiment: all stores land in slot 0 (stay in L2), results wrong
+    __builtin_amdgcn_raw_buffer_store_b96(v, w.rs, w.off, (u32)g * w.row_bytes, 0);
+#else
+    __builtin_amdgcn_raw_buffer_store_b96(v, w.rs, w.off, (base + (u32)g) * w.row_bytes, 0);
+#endif
   }
 }
 
@@ -91,25 +101,22 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   const u32 K = sa.K;
   const u32 threads = a.threads;
   u32 *ws = sa.ws;
-  constexpr u32 G = WS_GROUPS;
-  const u32 rowb = threads * 12u;  // bytes per workspace row
+  ws_ref wr;
+  wr.rs = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)(WS_GROUPS * K * threads * 12u), 0x00020000);
+  wr.row_bytes = threads * 12u;
+  wr.off = off;
 
   auto load_rec = [&](StreamRec &r, u32 id) {
-    const ws_rsrc rs = ws_slot(ws, threads, G, id);
     u32 wv[18];
-    ws_load<0, 18>(wv, rs, off, rowb);
+    ws_load<0, 18>(wv, wr, id);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
       r.x.l[i] = wv[i];
       r.y.l[i] = wv[9 + i];
     }
   };
-  auto load_p = [&](fe &q, u32 id) {
-    const ws_rsrc rs = ws_slot(ws, threads, G, id);
-    ws_load<18, 9>(q.l, rs, off, rowb);
-  };
+  auto load_p = [&](fe &q, u32 id) { ws_load<18, 9>(q.l, wr, id); };
   auto store_all = [&](u32 id, const fe &x, const fe &y, const fe &pp) {
-    const ws_rsrc rs = ws_slot(ws, threads, G, id);
     u32 wv[27];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -117,11 +124,16 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       wv[9 + i] = y.l[i];
       wv[18 + i] = pp.l[i];
     }
-#ifdef KG_EXP_NO_XY  // timing experiment only (results wrong)
-    ws_store<6, G - 1>(rs, off, rowb, wv + 18);
-#else
-    ws_store<0, G - 1>(rs, off, rowb, wv);
-#endif
+    ws_store<0, 8>(wr, id, wv);
+  };
+  auto store_xy = [&](u32 id, const fe &x, const fe &y) {
+    u32 wv[18];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      wv[i] = x.l[i];
+      wv[9 + i] = y.l[i];
+    }
+    ws_store<0, 5>(wr, id, wv);
   };
   // history row of (step, slot): K * threads bytes per step
   auto hist_row = [&](u32 step, u32 id) { return sa.hist + ((u64)step * K + id) * threads; };
@@ -173,119 +185,137 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     for (int i = 0; i < 9; ++i) jx.l[i] = row[i];
     fe_sub_wide(dx, x, jx);
     fe_mul(acc, dx, acc);
-    store_all(k, x, y, acc);
+    if (k & 1) store_all(k, x, y, acc);
+    else store_xy(k, x, y);
   }
 
-  // ---- steps: pass `run` visits the ids descending when run is even (the prologue went up), ascending when odd ----
+  // one jump of the kangaroo in `rec` (slot id) given dx^-1; multiplies its next dx into acc, stores the new
+  // point (and, for the second kangaroo of a pair, the running product), reports a distinguished point
+  auto jump = [&](const StreamRec &rec, const fe &dxi, const fe &jx, const u32 *row, u32 jmp, u32 id, u32 run, bool with_p) {
+    fe jy;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) jy.l[i] = row[9 + i];
+    fe dy, s, p2, rx, tt, ry;
+    fe_sub_wide(dy, rec.y, jy);
+    fe_mul(s, dy, dxi);
+    fe_sqr(p2, s);
+    fe_sub2_wide(rx, p2, jx, rec.x);
+    fe_canon(rx);
+    fe_sub_wide(tt, rec.x, rx);
+    fe_mul(ry, tt, s);
+    fe_sub_wide(ry, ry, rec.y);
+    fe_weak(ry);
+    hist_row(run, id)[Tl] = (unsigned char)jmp;
+    {
+      const u32 *row2 = jt + (rx.l[0] & (NB_JUMP - 1)) * JT_STRIDE;
+      fe jx2, dx2;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) jx2.l[i] = row2[i];
+      fe_sub_wide(dx2, rx, jx2);
+      fe_mul(acc, dx2, acc);
+    }
+    if (with_p) store_all(id, rx, ry, acc);
+    else store_xy(id, rx, ry);
+
+    // distinguished point: (x.bits64[3] & dpMask) == 0   (math/gpu/compute.h:54)
+    const u32 top_hi = (rx.l[8] << 8) | (rx.l[7] >> 21);
+    const u32 top_lo = (rx.l[7] << 11) | (rx.l[6] >> 18);
+    const u64 p = T + (u64)id * threads;
+    const bool is_dp = ((top_hi & a.dp_mask_hi) | (top_lo & a.dp_mask_lo)) == 0 && p < a.n;
+    const unsigned long long m = __ballot(is_dp);
+    if (m != 0) {
+      const u32 lane = __lane_id();
+      const u32 leader = (u32)__ffsll(m) - 1;
+      u32 basep = 0;
+      if (lane == leader) basep = atomicAdd(a.out_count, (u32)__popcll(m));
+      basep = __shfl(basep, (int)leader);
+      if (is_dp) {
+        const u32 pos = basep + (u32)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < a.max_found) {
+          DpItemDev *it = a.out + pos;
+          u32 w[8];
+          fe_to_words(w, rx);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) it->x[i] = w[i];
+          dlt<DW> dl;
+          travelled(dl, run, id);  // steps before this one, from the history (this branch is rare)
+          delta_add<DW>(dl.w, jdist + jmp * DW);
+          add_dist_256<DW>(w, a.D, a.cap, p, dl);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) it->d[i] = w[i];
+          it->kidx = p;
+        }
+      }
+    }
+  };
+
+  // ---- steps: pass `run` visits the ids descending when run is even (the prologue went up), ascending when odd.
+  // Position s of a pass holds id(s) = asc ? s : K-1-s.  Kangaroos go in pairs (A at s, B at s+1, K is even) and
+  // only B's running product is written: HBM writes, not reads, are what limits this kernel.  The product of
+  // the dx still to come after B, q_B, was stored by the previous pass in slot id_B + dir (the second of its pair
+  // then); q_A = q_B * dx_B costs one extra multiplication per pair.
   u32 run = 0;
 #pragma unroll 1
   do {
     const bool asc = (run & 1) != 0;
-    const int dir = asc ? 1 : -1;
-    // operands of the first kangaroo of the pass: requested before the inversion, which hides the latency
-    StreamRec cur;
-    fe cur_q;
-    {
-      const u32 id0 = asc ? 0u : K - 1;
-      load_rec(cur, id0);
-      const u32 nb0 = K > 1 ? (u32)((int)id0 + dir) : id0;
-      load_p(cur_q, nb0);
-    }
+    auto id_at = [&](u32 s) { return asc ? s : K - 1 - s; };
+    // operands of the first pair: requested before the inversion, which hides the latency
+    StreamRec A, B;
+    fe QB;
+    load_rec(A, id_at(0));
+    load_rec(B, id_at(1));
+    load_p(QB, K > 2 ? id_at(2) : id_at(1));
     fe u;
     fe_inv(u, acc);
+    // The first operands have long arrived.  Saying so matters: the compiler's wait-count bookkeeping merges
+    // the loop entry with the back edge, and a load still "pending" at the entry turns into a wait on the
+    // previous body's STORES at the top of every iteration (vmcnt counts loads and stores in order).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc.l[i] = (i == 0);
 
 #pragma unroll 1
-    for (u32 t = 0; t < K; ++t) {
-      const u32 id = asc ? t : K - 1 - t;
-      // prefetch the next kangaroo (clamped at the end of the pass: loads a valid slot that is not used)
-      StreamRec nxt;
-      fe nxt_q;
+    for (u32 s = 0; s < K; s += 2) {
+      const u32 idA = id_at(s), idB = id_at(s + 1);
+      const bool last = s + 2 >= K;
+      // prefetch the next pair (clamped at the end of the pass: valid slots, values unused)
+      StreamRec nA, nB;
+      fe nQB;
       {
-        const u32 tn = t + 1 < K ? t + 1 : t;
-        const u32 idn = asc ? tn : K - 1 - tn;
-        int nbn = (int)idn + dir;
-        nbn = nbn < 0 ? 0 : (nbn > (int)K - 1 ? (int)K - 1 : nbn);
-        load_rec(nxt, idn);
-        load_p(nxt_q, (u32)nbn);
+        const u32 s2 = last ? s : s + 2;
+        load_rec(nA, id_at(s2));
+        load_rec(nB, id_at(s2 + 1));
+        load_p(nQB, s2 + 2 < K ? id_at(s2 + 2) : id_at(s2 + 1));
       }
       __builtin_amdgcn_sched_barrier(0);
 
-      const u32 jmp = cur.x.l[0] & (NB_JUMP - 1);
-      const u32 *row = jt + jmp * JT_STRIDE;
-      fe jx, jy;
+      const u32 jmpA = A.x.l[0] & (NB_JUMP - 1), jmpB = B.x.l[0] & (NB_JUMP - 1);
+      const u32 *rowA = jt + jmpA * JT_STRIDE, *rowB = jt + jmpB * JT_STRIDE;
+      fe jxA, jxB, dxA, dxB, dxiA, dxiB;
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
-        jx.l[i] = row[i];
-        jy.l[i] = row[9 + i];
+        jxA.l[i] = rowA[i];
+        jxB.l[i] = rowB[i];
       }
-      fe dx, dxi;
-      // dx_id^-1 = u * (product of the ids still to come in this pass)
-      if (t + 1 < K) {
-        fe_mul(dxi, cur_q, u);
-        fe_sub_wide(dx, cur.x, jx);
-        fe_mul(u, dx, u);
-      } else {
-        dxi = u;
+      fe_sub_wide(dxA, A.x, jxA);
+      fe_sub_wide(dxB, B.x, jxB);
+      if (!last) {
+        fe qA;
+        fe_mul(qA, dxB, QB);
+        fe_mul(dxiA, qA, u);
+        fe_mul(u, dxA, u);
+        fe_mul(dxiB, QB, u);
+        fe_mul(u, dxB, u);
+      } else {  // nothing comes after B: q_B = 1
+        fe_mul(dxiA, dxB, u);
+        fe_mul(u, dxA, u);
+        dxiB = u;
       }
-      fe dy, s, p2, rx, tt, ry;
-      fe_sub_wide(dy, cur.y, jy);
-      fe_mul(s, dy, dxi);
-      fe_sqr(p2, s);
-      fe_sub2_wide(rx, p2, jx, cur.x);
-      fe_canon(rx);
-      fe_sub_wide(tt, cur.x, rx);
-      fe_mul(ry, tt, s);
-      fe_sub_wide(ry, ry, cur.y);
-      fe_weak(ry);
-#ifndef KG_EXP_NO_HIST  // timing experiment only (results wrong)
-      hist_row(run, id)[Tl] = (unsigned char)jmp;
-#endif
-
-      // next step's dx and running product
-      {
-        const u32 *row2 = jt + (rx.l[0] & (NB_JUMP - 1)) * JT_STRIDE;
-        fe jx2, dx2;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) jx2.l[i] = row2[i];
-        fe_sub_wide(dx2, rx, jx2);
-        fe_mul(acc, dx2, acc);
-      }
-      store_all(id, rx, ry, acc);
-
-      // distinguished point: (x.bits64[3] & dpMask) == 0   (math/gpu/compute.h:54)
-      const u32 top_hi = (rx.l[8] << 8) | (rx.l[7] >> 21);
-      const u32 top_lo = (rx.l[7] << 11) | (rx.l[6] >> 18);
-      const u64 p = T + (u64)id * threads;
-      const bool is_dp = ((top_hi & a.dp_mask_hi) | (top_lo & a.dp_mask_lo)) == 0 && p < a.n;
-      const unsigned long long m = __ballot(is_dp);
-      if (m != 0) {
-        const u32 lane = __lane_id();
-        const u32 leader = (u32)__ffsll(m) - 1;
-        u32 basep = 0;
-        if (lane == leader) basep = atomicAdd(a.out_count, (u32)__popcll(m));
-        basep = __shfl(basep, (int)leader);
-        if (is_dp) {
-          const u32 pos = basep + (u32)__popcll(m & ((1ull << lane) - 1ull));
-          if (pos < a.max_found) {
-            DpItemDev *it = a.out + pos;
-            u32 w[8];
-            fe_to_words(w, rx);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) it->x[i] = w[i];
-            dlt<DW> dl;
-            travelled(dl, run, id);  // steps before this one, from the history (this branch is rare)
-            delta_add<DW>(dl.w, jdist + jmp * DW);
-            add_dist_256<DW>(w, a.D, a.cap, p, dl);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) it->d[i] = w[i];
-            it->kidx = p;
-          }
-        }
-      }
-      cur = nxt;
-      cur_q = nxt_q;
+      jump(A, dxiA, jxA, rowA, jmpA, idA, run, false);
+      jump(B, dxiB, jxB, rowB, jmpB, idB, run, true);
+      A = nA;
+      B = nB;
+      QB = nQB;
     }
   } while (++run < a.nb_run);
 

@@ -34,7 +34,7 @@ def _engine(groups, per_group, case, nb_run=None, k=None, u=None, w=None, mode=N
 # streaming kernel: (mode, kangaroos per lane, -, waves/SIMD); 64 per lane leaves half of the only workgroup padding
 VARIANTS = [("reg", 1, 0, 2), ("reg", 4, 0, 2), ("reg", 8, 0, 2), ("reg", 8, 0, 1), ("reg", 12, 0, 1), ("reg", 8, 4, 2),
             ("reg", 12, 4, 1), ("reg", 16, 4, 1), ("reg", 16, 2, 1),
-            ("stream", 1, None, 2), ("stream", 2, None, 2), ("stream", 5, None, 3), ("stream", 16, None, 2),
+            ("stream", 2, None, 2), ("stream", 4, None, 2), ("stream", 6, None, 3), ("stream", 16, None, 2),
             ("stream", 64, None, 2), ("stream", 10, None, 1)]
 
 
