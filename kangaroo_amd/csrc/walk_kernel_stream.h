@@ -38,6 +38,13 @@ struct StreamRec {
 
 // Workspace access through a buffer descriptor: an offset outside the workspace is dropped by the hardware
 // bounds check instead of faulting, and there is no per-access address arithmetic on the VALU.
+// cache policy of the workspace accesses (aux operand of the buffer instructions: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef KG_WS_AUX_LD
+#define KG_WS_AUX_LD 0
+#endif
+#ifndef KG_WS_AUX_ST
+#define KG_WS_AUX_ST 0
+#endif
 typedef __amdgpu_buffer_rsrc_t ws_rsrc;
 typedef u32 u32x3 __attribute__((ext_vector_type(3)));
 constexpr u32 WS_GROUPS = 9;
@@ -55,7 +62,7 @@ __device__ __forceinline__ void ws_load(u32 *dst, const ws_ref &w, u32 id) {
   const u32 base = id * WS_GROUPS;
 #pragma unroll
   for (int g = G0; g <= G1; ++g) {
-    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(w.rs, w.off, (base + (u32)g) * w.row_bytes, 0);
+    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(w.rs, w.off, (base + (u32)g) * w.row_bytes, KG_WS_AUX_LD);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int i = 3 * g + c - FIRST;
@@ -73,9 +80,9 @@ __device__ __forceinline__ void ws_store(const ws_ref &w, u32 id, const u32 *src
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = src[3 * (g - G0) + c];
 #ifdef KG_EXP_STORE_SLOT0  // timing experiment: all stores land in slot 0 (stay in L2), results wrong
-    __builtin_amdgcn_raw_buffer_store_b96(v, w.rs, w.off, (u32)g * w.row_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b96(v, w.rs, w.off, (u32)g * w.row_bytes, KG_WS_AUX_ST);
 #else
-    __builtin_amdgcn_raw_buffer_store_b96(v, w.rs, w.off, (base + (u32)g) * w.row_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b96(v, w.rs, w.off, (base + (u32)g) * w.row_bytes, KG_WS_AUX_ST);
 #endif
   }
 }
