@@ -302,7 +302,8 @@ extern "C" int kg_create(int gpu_id, int groups, int per_group, uint32_t max_fou
   e->streaming = stream_mode();
   // the streaming kernel addresses its workspace (108 B per kangaroo) through one 32-bit buffer descriptor:
   // herds beyond 4 GiB of workspace (39 M kangaroos) run on the register-resident kernel
-  if (e->streaming && (e->n + 4096) * (u64)(WS_GROUPS * 12) >= (1ull << 32)) e->streaming = false;
+  // (padding: at most 256 lanes x K <= 1024 kangaroos)
+  if (e->streaming && (e->n + 256 * 1024) * (u64)(WS_GROUPS * 12) >= (1ull << 32)) e->streaming = false;
   if (e->streaming) {
     // K kangaroos per lane such that the herd fills about KG_W (2) waves per SIMD; KG_K overrides
     const u64 lanes = (u64)e->cus * 4 * 64 * (u64)env_int("KG_W", 2);
