@@ -66,6 +66,25 @@ def test_dp_stream_and_state_match_oracle(mode, k, u, w):
     e.close()
 
 
+@pytest.mark.parametrize("mode,groups,per_group,k", [("stream", 3, 7, None), ("stream", 1, 1, None), ("stream", 5, 3, 6),
+                                                     ("reg", 3, 7, 16), ("reg", 1, 1, 8)])
+def test_ragged_herd_sizes(mode, groups, per_group, k):
+    """Herds that do not fill the last workgroup (2688, 128, 1920 kangaroos): padding lanes walk a copy of
+    kangaroo 0 and must never report; every real kangaroo matches the oracle."""
+    n = 128 * groups * per_group
+    case = make_case(64, n, seed=500 + n, dp_bits=4)
+    e = _engine(groups, per_group, case, nb_run=33, k=k, mode=mode)
+    px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
+    e.callKernel()
+    got = e.Launch()
+    assert int(got["kIdx"].max()) < n
+    assert dp_multiset(got) == oracle_dps(case, px, py, d, 33)
+    assert dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 33)
+    gx, gy, gd = e.GetKangaroos()
+    assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
+    e.close()
+
+
 @pytest.mark.parametrize("mode", ["stream", "reg"])
 def test_default_nb_run_256_and_125_bit_range(mode):
     """NB_RUN = 256 (constants.h:21) with the benchmark's 125-bit jump table (3-word distance delta)."""
