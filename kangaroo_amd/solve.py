@@ -37,7 +37,13 @@ def solve_key(range_start, range_end, pub, grid=(0, 0), gpu_id=0, dp_bits=None, 
     try:
         n = eng.nbKangaroo
         if dp_bits is None:
-            dp_bits = suggested_dp(sv.range_power, n)
+            # the reference's suggestion, raised if needed so that a launch cannot overflow the DP ring
+            # (the reference would exit with "items lost", engine.cu:506-510)
+            import math
+
+            ring = max(65536 * 2, min(2 * n, 1 << 22))
+            per_launch = n * (nb_run or 256)
+            dp_bits = max(suggested_dp(sv.range_power, n), math.ceil(math.log2(per_launch / (ring / 2))))
         rng = host.Rng(seed)
         # CreateHerd (core/kangaroo.cpp:521-573): the distances with the reference's RNG draws on the host,
         # the points d*G (+ key for wild) on the GPU (kg_herd_from_distances)

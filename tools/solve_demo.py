@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Known-key solve on one GPU (BASELINE configs 2/3 on a single device).
+Usage: python tools/solve_demo.py <range_bits> [dp_bits] [gx gy]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from kangaroo_amd import host, solve
+
+bits = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dp = int(sys.argv[2]) if len(sys.argv) > 2 else None
+grid = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (0, 0)
+priv = (0xD1B54A32D192ED03C0FFEE1234567890ABCDEF % (1 << (bits - 1))) | (1 << (bits - 1))
+pub = host.ec_mul_g(priv)
+last = [time.time()]
+
+
+def progress(launches, n_dp, table):
+    if time.time() - last[0] > 20:
+        last[0] = time.time()
+        print(f"  launch {launches}: {n_dp} DPs, table {table}", flush=True)
+
+
+t0 = time.time()
+found, st = solve.solve_key(0, (1 << bits) - 1, pub, grid=grid, dp_bits=dp, seed=11, progress=progress)
+dt = time.time() - t0
+print(f"range 2^{bits}: key {'FOUND' if found == priv else 'NOT FOUND'} = {found:#x}" if found else "not found")
+print(f"  {st['device']}: kangaroos {st['kangaroos']}, DP bits {st['dp_bits']}, launches {st['launches']}, "
+      f"jumps 2^{__import__('math').log2(st['jumps']):.2f}, DPs {st['dps']}, table {st['table']}, dead {st['dead']}")
+print(f"  walk {st['seconds']:.1f} s ({st['jumps'] / st['seconds'] / 1e9:.2f} G jumps/s incl. host ingest), total {dt:.1f} s")
+sys.exit(0 if found == priv else 1)
