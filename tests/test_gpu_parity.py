@@ -152,3 +152,33 @@ def test_dp_zero_bits_every_point_and_overflow_report(mode):
         e.Collect()
     assert "items lost" in str(ei.value) and e.lost == 8192 * 64 - 131072
     e.close()
+
+
+def test_two_engines_in_one_process_from_two_threads():
+    """The reference runs one GPUEngine per host thread (core/kangaroo.cpp:780-786); two engines on one device,
+    driven concurrently, must not disturb each other (own stream, own buffers, per-thread error state)."""
+    import threading
+
+    results = {}
+
+    def run(tag, seed, mode):
+        case = make_case(64, 128 * 1 * 64, seed=seed, dp_bits=5)
+        e = _engine(1, 64, case, nb_run=48, mode=mode)
+        px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
+        ok = True
+        e.callKernel()
+        for _ in range(3):
+            ok &= dp_multiset(e.Launch()) == oracle_dps(case, px, py, d, 48)
+        ok &= dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 48)
+        gx, gy, gd = e.GetKangaroos()
+        ok &= np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
+        e.close()
+        results[tag] = ok
+
+    # engines are created one after the other (the KG_* knobs are process environment), then run together
+    th = [threading.Thread(target=run, args=("a", 21, "stream")), threading.Thread(target=run, args=("b", 22, "stream"))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert results == {"a": True, "b": True}
