@@ -677,6 +677,15 @@ extern "C" int kg_kick(kg_engine *e) {
     sa.hist = (unsigned char *)e->ws + (size_t)WS_GROUPS * 3 * (size_t)e->K * (size_t)e->threads * sizeof(u32);
     sa.K = (u32)e->K;
     hipLaunchKernelGGL(sv->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, sa);
+    HIPCHK(hipGetLastError());
+    // distances: D += sum over the launch's jump-index history (inside the timed region)
+    const u32 sum_grid = (u32)((e->cap + WALK_BLOCK - 1) / WALK_BLOCK);
+    if (e->DW == 3)
+      hipLaunchKernelGGL(kg_hist_sum_kernel<3>, dim3(sum_grid), dim3(WALK_BLOCK), 0, e->stream, sa.hist, e->jt, e->D,
+                         e->cap, e->n, e->threads, (u32)e->K, e->nb_run);
+    else
+      hipLaunchKernelGGL(kg_hist_sum_kernel<8>, dim3(sum_grid), dim3(WALK_BLOCK), 0, e->stream, sa.hist, e->jt, e->D,
+                         e->cap, e->n, e->threads, (u32)e->K, e->nb_run);
   } else {
     hipLaunchKernelGGL(v->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, a);
   }

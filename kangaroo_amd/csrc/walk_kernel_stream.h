@@ -144,11 +144,12 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   };
   // history row of (step, slot): K * threads bytes per step
   auto hist_row = [&](u32 step, u32 id) { return sa.hist + ((u64)step * K + id) * threads; };
-  // distance travelled by slot id in steps [0, steps): sum of the jump distances in its history
+  // distance travelled by slot id in steps [0, steps): sum of the jump distances in its history (used by the
+  // lanes that report a distinguished point; the end-of-launch sums are kg_hist_sum_kernel's job)
   auto travelled = [&](dlt<DW> &sum, u32 steps, u32 id) {
 #pragma unroll
     for (int i = 0; i < DW; ++i) sum.w[i] = 0u;
-    constexpr u32 CH = 32;  // history bytes requested together, so that their latencies overlap
+    constexpr u32 CH = 4;  // history bytes requested together (rare path: kept small, it costs SGPRs)
 #pragma unroll 1
     for (u32 r0 = 0; r0 < steps; r0 += CH) {
       u32 j[CH];
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     }
   } while (++run < a.nb_run);
 
-  // ---- epilogue: workspace -> X/Y planes (canonical), D += distance travelled ----
+  // ---- epilogue: workspace -> X/Y planes (canonical); the distances are summed by kg_hist_sum_kernel ----
 #pragma unroll 1
   for (u32 k = 0; k < K; ++k) {
     StreamRec r;
@@ -341,12 +342,38 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     fe_to_words(w, r.y);
 #pragma unroll
     for (int i = 0; i < 4; ++i) a.Y[(u64)i * a.cap + p] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
-    dlt<DW> dl;
-    travelled(dl, a.nb_run, k);
-    add_dist_256<DW>(w, a.D, a.cap, p, dl);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a.D[(u64)i * a.cap + p] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
   }
+}
+
+// End of launch: D[p] += sum of the jump distances in kangaroo p's history.  One thread per kangaroo, full
+// occupancy, the history rows are lane-contiguous bytes (1 B per jump read once).
+template <int DW>
+__global__ void __launch_bounds__(WALK_BLOCK) kg_hist_sum_kernel(const unsigned char *hist, const JumpTableDev *jtab, u64 *D,
+                                                                 u64 cap, u64 n, u32 threads, u32 K, u32 nb_run) {
+  __shared__ u32 jdist[NB_JUMP * DW];
+  for (u32 i = threadIdx.x; i < NB_JUMP * DW; i += WALK_BLOCK) jdist[i] = jtab->dist[i / DW][i % DW];
+  __syncthreads();
+  const u64 p = (u64)blockIdx.x * WALK_BLOCK + threadIdx.x;
+  if (p >= cap) return;
+  const u32 k = (u32)(p / threads), lane = (u32)(p % threads);
+  const unsigned char *col = hist + (u64)k * threads + lane;  // + step * K * threads
+  const u64 step_stride = (u64)K * threads;
+  dlt<DW> sum;
+#pragma unroll
+  for (int i = 0; i < DW; ++i) sum.w[i] = 0u;
+  u32 r = 0;
+  for (; r + 8 <= nb_run; r += 8) {
+    u32 j[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) j[i] = col[(u64)(r + i) * step_stride];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) delta_add<DW>(sum.w, jdist + j[i] * DW);
+  }
+  for (; r < nb_run; ++r) delta_add<DW>(sum.w, jdist + col[(u64)r * step_stride] * DW);
+  u32 w[8];
+  add_dist_256<DW>(w, D, cap, p, sum);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) D[(u64)i * cap + p] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
 }
 
 constexpr size_t walk_stream_lds_bytes(int DW) { return (size_t)(NB_JUMP * JT_STRIDE + NB_JUMP * DW) * sizeof(u32); }
