@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   extern __shared__ u32 lds[];
   u32 *jt = lds;                           // [64][JT_STRIDE]
   u32 *jdist = lds + NB_JUMP * JT_STRIDE;  // [64][DW]
+  u32 *inv_ex = jdist + NB_JUMP * DW;      // [8][9][64]: products in, inverses out (shared inversion)
 
   const u32 tid = threadIdx.x;
   for (u32 i = tid; i < NB_JUMP * 18; i += WALK_BLOCK) {
@@ -274,7 +275,51 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     load_rec(B, id_at(1));
     load_p(QB, K > 2 ? id_at(2) : id_at(1));
     fe u;
+#ifdef KG_STREAM_PRIVATE_INV
     fe_inv(u, acc);
+#else
+    // One inversion for the four waves of the workgroup: lane l of every wave posts its product, the wave
+    // whose turn it is inverts the product of the four and hands each wave the inverse of its own (3 + 6
+    // multiplications against three inversions saved).  The other three waves wait at the barrier; their
+    // SIMDs are not idle meanwhile, each holds a wave of another workgroup.
+    {
+      const u32 wave = tid >> 6, lane = tid & 63u;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) inv_ex[(wave * 9 + i) * 64 + lane] = acc.l[i];
+      __syncthreads();
+      if (wave == (run & 3u)) {
+        fe a0, a1, a2, a3, p01, p23, t, iv, i01, i23, r;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          a0.l[i] = inv_ex[(0 * 9 + i) * 64 + lane];
+          a1.l[i] = inv_ex[(1 * 9 + i) * 64 + lane];
+          a2.l[i] = inv_ex[(2 * 9 + i) * 64 + lane];
+          a3.l[i] = inv_ex[(3 * 9 + i) * 64 + lane];
+        }
+        fe_mul(p01, a0, a1);
+        fe_mul(p23, a2, a3);
+        fe_mul(t, p01, p23);
+        fe_inv(iv, t);
+        fe_mul(i01, iv, p23);
+        fe_mul(i23, iv, p01);
+        fe_mul(r, i01, a1);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) inv_ex[((4 + 0) * 9 + i) * 64 + lane] = r.l[i];
+        fe_mul(r, i01, a0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) inv_ex[((4 + 1) * 9 + i) * 64 + lane] = r.l[i];
+        fe_mul(r, i23, a3);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) inv_ex[((4 + 2) * 9 + i) * 64 + lane] = r.l[i];
+        fe_mul(r, i23, a2);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) inv_ex[((4 + 3) * 9 + i) * 64 + lane] = r.l[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 9; ++i) u.l[i] = inv_ex[((4 + wave) * 9 + i) * 64 + lane];
+    }
+#endif
     // The first operands have long arrived.  Saying so matters: the compiler's wait-count bookkeeping merges
     // the loop entry with the back edge, and a load still "pending" at the entry turns into a wait on the
     // previous body's STORES at the top of every iteration (vmcnt counts loads and stores in order).
@@ -376,6 +421,8 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_hist_sum_kernel(const unsigned 
   for (int i = 0; i < 4; ++i) D[(u64)i * cap + p] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
 }
 
-constexpr size_t walk_stream_lds_bytes(int DW) { return (size_t)(NB_JUMP * JT_STRIDE + NB_JUMP * DW) * sizeof(u32); }
+constexpr size_t walk_stream_lds_bytes(int DW) {
+  return (size_t)(NB_JUMP * JT_STRIDE + NB_JUMP * DW + 8 * 9 * 64) * sizeof(u32);
+}
 
 }  // namespace kg
