@@ -70,21 +70,33 @@ __device__ __forceinline__ void ws_load(u32 *dst, const ws_ref &w, u32 id) {
     }
   }
 }
+// Store-data hazard, found on MI355X with the full-size herd (tests/test_gpu_parity.py, 512 workgroups): a
+// buffer_store_dwordx3 whose data VGPRs are overwritten by the VALU instruction right behind it can write the
+// NEW values for lanes 12-15 of every 16 (the last quad of a row).  The compiler pads this hazard only for wide
+// stores WITHOUT an SGPR offset (its model says a register soffset is safe; here it is not) and happily
+// reuses the registers of the last limbs in the very next instruction.  ws_hold() is an s_nop that names the
+// stored registers as inputs: nothing may overwrite them before it, and it is two wait states long.
+__device__ __forceinline__ void ws_hold(const u32x3 &a, const u32x3 &b, const u32x3 &c) {
+  asm volatile("s_nop 1" ::"v"(a), "v"(b), "v"(c));
+}
 // groups [G0, G1] of slot id <- src, where src[i] is word 3 * G0 + i of the slot
 template <int G0, int G1>
 __device__ __forceinline__ void ws_store(const ws_ref &w, u32 id, const u32 *src) {
+  static_assert((G1 - G0 + 1) % 3 == 0, "ws_hold takes the groups three at a time");
   const u32 base = id * WS_GROUPS;
+  u32x3 v[G1 - G0 + 1];
 #pragma unroll
   for (int g = G0; g <= G1; ++g) {
-    u32x3 v;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) v[c] = src[3 * (g - G0) + c];
+    for (int c = 0; c < 3; ++c) v[g - G0][c] = src[3 * (g - G0) + c];
 #ifdef KG_EXP_STORE_SLOT0  // timing experiment: all stores land in slot 0 (stay in L2), results wrong
-    __builtin_amdgcn_raw_buffer_store_b96(v, w.rs, w.off, (u32)g * w.row_bytes, KG_WS_AUX_ST);
+    __builtin_amdgcn_raw_buffer_store_b96(v[g - G0], w.rs, w.off, (u32)g * w.row_bytes, KG_WS_AUX_ST);
 #else
-    __builtin_amdgcn_raw_buffer_store_b96(v, w.rs, w.off, (base + (u32)g) * w.row_bytes, KG_WS_AUX_ST);
+    __builtin_amdgcn_raw_buffer_store_b96(v[g - G0], w.rs, w.off, (base + (u32)g) * w.row_bytes, KG_WS_AUX_ST);
 #endif
   }
+#pragma unroll
+  for (int g = G1 - G0 - 2; g >= 0; g -= 3) ws_hold(v[g], v[g + 1], v[g + 2]);
 }
 
 template <int DW, int W>

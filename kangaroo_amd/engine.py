@@ -242,7 +242,7 @@ class GPUEngine:
         if rc == KG_ERR_LOST:
             # the reference prints this and exits (engine.cu:506-510)
             raise KgError(rc, self._L.kg_last_error().decode())
-        return self._items[: n.value]
+        return self._items[: n.value].copy()  # the staging array is reused by the next call
 
     def Launch(self, spinWait=False):
         """Wait for the launch in flight, return its DPs (structured array x,d,kIdx), start the next."""

@@ -182,3 +182,82 @@ def test_two_engines_in_one_process_from_two_threads():
     for t in th:
         t.join()
     assert results == {"a": True, "b": True}
+
+
+def test_full_size_bench_herd_sampled_walks_and_point_distance_invariant():
+    """BASELINE config 2 at full size: 512 x 128 grid = 8 388 608 kangaroos, NB_RUN = 256, 125-bit jump table.
+    Every kangaroo walks alone, so re-walking a sample of them with the oracle pins the launch at any herd size:
+    final x, y, distance and every reported DP of the sampled kangaroos, bit for bit.  Over the whole herd the
+    size-independent invariant is P_i = d_i * G (the synthetic herd starts on it and every jump keeps it), checked on
+    a second, larger sample with the host EC code, and every DP anyone reported must satisfy the mask."""
+    from kangaroo_amd import GPUEngine, host
+
+    e = GPUEngine(512, 128, 0, 1 << 17)
+    n = e.nbKangaroo
+    assert n == 8388608 and "stream" in e.KernelName()
+    threads = n // e.KernelInfo()["k_per_lane"]
+    px, py, d = host.synthetic_herd(n)
+    jd, jx, jy, _ = host.create_jump_table(125)
+    dp_mask = 0xFFFF000000000000  # 16 bits: ~32768 DPs per launch
+    e.SetWildOffset(((1 << 125) - 1) >> 1)
+    e.SetParams(dp_mask, jd, jx, jy)
+    e.SetKangaroos(px, py, d)
+    e.callKernel()
+    items = np.concatenate([e.Launch(), e.Collect()])  # two launches: both pass directions, state carried over
+    gx, gy, gd = e.GetKangaroos()
+    e.close()
+
+    rng = np.random.default_rng(12345)
+    edges = [0, 1, 63, 64, 255, 256, threads - 1, threads, threads + 1, 2 * threads - 1, n // 2 - 1, n // 2, n - threads,
+             n - 257, n - 256, n - 65, n - 64, n - 2, n - 1]
+    sample = np.unique(np.concatenate([np.array(edges), rng.integers(0, n, 300)])).astype(np.int64)
+    sx, sy, sd = px[sample].copy(), py[sample].copy(), d[sample].copy()
+    ref = K.walk(sx, sy, sd, 512, dp_mask, jd, jx, jy, cap=1 << 16)
+    assert np.array_equal(gx[sample], sx) and np.array_equal(gy[sample], sy) and np.array_equal(gd[sample], sd)
+    ref_dps = sorted((int(sample[k]), x, dd) for _, k, x, dd in ref)
+    pos = {int(k): True for k in sample}
+    got_dps = [t for t in dp_multiset(items[np.isin(items["kIdx"], sample)]) if t[0] in pos]
+    assert got_dps == ref_dps
+
+    # all DPs: mask, index range, plausible count (binomial, p = 2^-16 over 2 * 256 * n jumps)
+    assert int(items["kIdx"].max()) < n
+    assert not np.any(items["x"][:, 3] & np.uint64(dp_mask))
+    expect = 2 * 256 * n / 65536
+    assert abs(len(items) - expect) < 6 * expect ** 0.5
+    # P = d * G on 4096 kangaroos and on 512 of the reported DPs
+    chk = rng.integers(0, n, 4096)
+    hx, _ = host.ec_mul_g_batch(gd[chk])
+    assert np.array_equal(hx, gx[chk])
+    some = items[rng.integers(0, len(items), 512)]
+    hx, _ = host.ec_mul_g_batch(np.ascontiguousarray(some["d"]))
+    assert np.array_equal(hx, some["x"])
+
+
+def test_512_workgroups_every_kangaroo_matches_oracle():
+    """Two workgroups per CU on every CU (512 workgroups, 2 kangaroos per lane, 262 144 kangaroos), every kangaroo
+    compared.  This is the smallest herd that showed the wide-store data hazard fixed by ws_hold()
+    (walk_kernel_stream.h): y of a few waves' lanes 12-15 mod 16 came back wrong after ONE step, and only in
+    workgroups 256 and up, which no herd of the other tests reaches."""
+    from kangaroo_amd import GPUEngine, host
+
+    os.environ["KG_K"] = "2"
+    try:
+        e = GPUEngine(16, 128, 0, 1 << 16)
+    finally:
+        os.environ.pop("KG_K", None)
+    n = e.nbKangaroo
+    assert n == 262144 and e.KernelInfo()["grid"] == 512 and "stream" in e.KernelName()
+    px, py, d = host.synthetic_herd(n)
+    jd, jx, jy, _ = host.create_jump_table(125)
+    dp_mask = 0xFFF0000000000000
+    e.SetWildOffset(((1 << 125) - 1) >> 1)
+    e.SetParams(dp_mask, jd, jx, jy)
+    e.SetNbRun(5)
+    e.SetKangaroos(px, py, d)
+    e.callKernel()
+    items = np.concatenate([e.Launch(), e.Launch(), e.Collect()])
+    gx, gy, gd = e.GetKangaroos()
+    e.close()
+    ref = K.walk(px, py, d, 15, dp_mask, jd, jx, jy, cap=1 << 16)
+    assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
+    assert dp_multiset(items) == sorted((k, x, dd) for _, k, x, dd in ref)
