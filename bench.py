@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--grid", type=str, default="", help="x,y (kangaroos = 128*x*y per GPU); default engine grid")
     ap.add_argument("--nb-run", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", type=int, default=2048, help="kangaroos re-derived from their distance after the run")
     args = ap.parse_args()
 
     from kangaroo_amd import GPUEngine, dist, host
@@ -132,6 +133,22 @@ def main():
     elapsed = dist.max_over_ranks(elapsed)
     total_kangaroos = dist.sum_over_ranks(n)
 
+    # self-check, outside the timed region: a sample of the herd must still satisfy P_i = d_i*G (+ key for the
+    # wild, odd-indexed half) after all the jumps; host EC code of the product library, not the oracle
+    gxs, gys, gds = eng.GetKangaroos()
+    sample = np.random.default_rng(1234 + rank).integers(0, n, args.check)
+    hx, hy = host.ec_mul_g_batch(np.ascontiguousarray(gds[sample]))
+    bad = 0
+    for j, i in enumerate(sample):
+        pt = (host.to_int(hx[j]), host.to_int(hy[j]))
+        if i & 1:
+            pt = host.ec_add(pt, key)
+        bad += pt != (host.to_int(gxs[i]), host.to_int(gys[i]))
+    del gxs, gys, gds
+    bad = dist.sum_over_ranks(int(bad))
+    if bad:
+        raise RuntimeError(f"bench self-check failed: {bad} of {args.check * world} sampled kangaroos are off their track")
+
     jumps = total_kangaroos * args.nb_run * args.steps
     value = jumps / elapsed
     info = eng.KernelInfo()
@@ -168,7 +185,9 @@ def main():
         "config": {"workload": "BASELINE config 4: 125-bit range throughput, jump table seed 0x600DCAFE, DP mask 32 bits",
                    "kangaroos_per_gpu": n, "grid": [gx, gy], "nb_run": args.nb_run,
                    "kangaroos_per_lane": info["k_per_lane"], "delta_words": info["delta_words"],
-                   "lds_bytes_per_workgroup": info["lds_bytes"], "workgroups": info["grid"], "dps_seen": n_dp},
+                   "lds_bytes_per_workgroup": info["lds_bytes"], "workgroups": info["grid"], "dps_seen": n_dp,
+                   "self_check": {"invariant": "P_i == d_i*G (+ key for wild) after the timed launches",
+                                  "sampled_per_gpu": args.check, "bad": 0}},
         "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MAD32_PER_S / 1e12,
                      "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_PER_S, "traffic": traffic,
                      "kernel": eng.KernelName(), "kernel_ms_avg": avg_kernel_ms,
