@@ -346,14 +346,10 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       // prefetch the next pair (clamped at the end of the pass: valid slots, values unused)
       StreamRec nA, nB;
       fe nQB;
+      // A's successor is requested here, B's after A has jumped: two short bursts instead of one long one
+      // (the per-CU memory queue is what waves block on), and 25 fewer live registers
       const u32 s2 = last ? s : s + 2;
-#ifdef KG_EXP_SPLIT_PF  // experiment: the prefetch spread over the iteration instead of one burst at its top
       load_rec(nA, id_at(s2));
-#else
-      load_rec(nA, id_at(s2));
-      load_rec(nB, id_at(s2 + 1));
-      load_p(nQB, s2 + 2 < K ? id_at(s2 + 2) : id_at(s2 + 1));
-#endif
       __builtin_amdgcn_sched_barrier(0);
 
       const u32 jmpA = A.x.l[0] & (NB_JUMP - 1), jmpB = B.x.l[0] & (NB_JUMP - 1);
@@ -378,20 +374,11 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
         fe_mul(u, dxA, u);
         dxiB = u;
       }
-#if defined(KG_EXP_SPLIT_PF) && KG_EXP_SPLIT_PF == 2
-      __builtin_amdgcn_sched_barrier(0);
-      load_p(nQB, s2 + 2 < K ? id_at(s2 + 2) : id_at(s2 + 1));
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       jump(A, dxiA, jxA, rowA, jmpA, idA, run, false);
-#ifdef KG_EXP_SPLIT_PF
       __builtin_amdgcn_sched_barrier(0);
       load_rec(nB, id_at(s2 + 1));
-#if KG_EXP_SPLIT_PF != 2
       load_p(nQB, s2 + 2 < K ? id_at(s2 + 2) : id_at(s2 + 1));
-#endif
       __builtin_amdgcn_sched_barrier(0);
-#endif
       jump(B, dxiB, jxB, rowB, jmpB, idB, run, true);
       A = nA;
       B = nB;
