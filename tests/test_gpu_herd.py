@@ -45,3 +45,29 @@ def test_scalar_edge_cases_against_oracle():
     ex, ey = host.ec_mul_g_batch(d)
     assert np.array_equal(gx, ex) and np.array_equal(gy, ey)
     e.close()
+
+
+def test_full_size_herd_sampled_against_host():
+    """The bench herd (512 x 128 grid, 8 388 608 kangaroos, 125-bit range): 4096 sampled start points and the edges
+    of the lane/slot layout equal d*G (+ key for the wild, odd-indexed half) computed by the host code."""
+    range_power = 125
+    width = (1 << range_power) - 1
+    key = host.ec_mul_g(0x0A5B3C1D2E7F9081726354453627180F % width)
+    e = GPUEngine(512, 128, 0, 65536)
+    n = e.nbKangaroo
+    assert n == 8388608
+    e.SetWildOffset(width >> 1)
+    d = host.herd_distances(host.Rng(7), range_power, width, n, 0)
+    e.HerdFromDistances(d, key)
+    gx, gy, gd = e.GetKangaroos()
+    e.close()
+    assert np.array_equal(gd, d)
+    rng = np.random.default_rng(3)
+    sample = np.unique(np.concatenate([np.array([0, 1, 63, 64, 255, 256, 65535, 65536, 131071, 131072, n // 2, n - 2, n - 1]),
+                                       rng.integers(0, n, 4096)]))
+    hx, hy = host.ec_mul_g_batch(np.ascontiguousarray(d[sample]))
+    for j, i in enumerate(sample):
+        pt = (host.to_int(hx[j]), host.to_int(hy[j]))
+        if i & 1:
+            pt = host.ec_add(pt, key)
+        assert pt == (host.to_int(gx[i]), host.to_int(gy[i])), int(i)
