@@ -15,11 +15,13 @@
 // cut into 9 groups of three words; group g of slot k is a row of `threads` 12-byte entries at row index
 // k * 9 + g, so that one buffer_load/store_dwordx3 moves 768 contiguous bytes per wavefront.
 // Distances are not carried through the steps at all: every jump appends its jump index (one byte) to a
-// history hist[step][slot][lane]; the distance travelled is summed from the history by the epilogue, and by the
-// few lanes that report a distinguished point.  1 byte per jump instead of reading and writing the delta.  The prologue converts X/Y planes into the workspace, the epilogue converts back and
-// adds the deltas to D, so the engine's resident format (walk_kernel.h) is unchanged.
+// history hist[step][slot][lane]; kg_hist_sum_kernel adds the jump distances of every kangaroo's history to D
+// after the walk, and the few lanes that report a distinguished point sum their own history up to that step.
+// 1 byte per jump instead of reading and writing the delta.  The prologue converts the X/Y planes into the
+// workspace, the epilogue converts back, so the engine's resident format (walk_kernel.h) is unchanged.
 //
-// The step itself is the fused pass of walk_kernel_rot.h: same arithmetic, same results.
+// The step itself is the fused pass of walk_kernel_rot.h: same arithmetic, same results.  The four waves of a
+// workgroup share one modular inversion per step through LDS.
 #pragma once
 #include "walk_kernel_rot.h"
 
