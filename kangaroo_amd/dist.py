@@ -90,3 +90,52 @@ def herd_shard(rank, world, n_per_rank, base=0x1234567, stride=0x9E3779B97F4A7C1
     """Start scalar of rank's synthetic herd: ranks own disjoint arithmetic progressions of distances."""
     assert 0 <= rank < world
     return (base + rank * n_per_rank * stride) % N_ORDER, stride
+
+
+def all_gather_array(arr):
+    """A fixed-size uint64 array from every rank -> [world, len] on every rank (control words of the solve loop)."""
+    rank, _, world = env_world()
+    arr = np.ascontiguousarray(arr, dtype=np.uint64)
+    if world == 1:
+        return arr.reshape(1, -1).copy()
+    import torch
+    import torch.distributed as dist
+
+    t = torch.from_numpy(arr.view(np.int64).copy()).to(_device())
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return np.stack([o.cpu().numpy().view(np.uint64) for o in outs])
+
+
+def all_gather_items(items):
+    """The DP exchange: every rank's distinguished points of one launch (structured array, any length) ->
+    the concatenation over ranks, in rank order, on every rank.
+
+    This is the one exchange step the reference's multi-GPU solve has — all GPU threads feed one DP table
+    (core/kangaroo.cpp:473-490).  With one process per GPU the table is sharded by x across the ranks
+    (solve.solve_key_multi) and the DP stream is all-gathered: 72 B per DP, a few hundred thousand DPs per
+    second and GPU at the reference's DP sizes, i.e. tens of MB/s against xGMI links of 150 GB/s.  Lengths
+    differ per rank, so the counts go first and the payload is padded to the longest."""
+    rank, _, world = env_world()
+    items = np.ascontiguousarray(items)
+    if world == 1:
+        return items.copy()
+    import torch
+    import torch.distributed as dist
+
+    dev = _device()
+    cnt = torch.tensor([len(items)], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    cnts = [int(c.item()) for c in cnts]
+    longest = max(cnts)
+    if longest == 0:
+        return items[:0].copy()
+    size = items.dtype.itemsize
+    buf = torch.zeros(longest * size, dtype=torch.uint8, device=dev)
+    if len(items):
+        buf[: len(items) * size] = torch.from_numpy(items.view(np.uint8).reshape(-1).copy()).to(dev)
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    parts = [outs[r][: cnts[r] * size].cpu().numpy().view(items.dtype) for r in range(world)]
+    return np.concatenate(parts)

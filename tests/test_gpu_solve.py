@@ -27,3 +27,14 @@ def test_known_key_is_recovered(name, lo, hi, priv, grid, dp):
     assert st["jumps"] == st["kangaroos"] * 256 * st["launches"]
     # Pollard kangaroo expects about 2 * sqrt(range) jumps (+ DP overhead); 64x that means something is broken
     assert st["jumps"] < 64 * 2 * (1 << (st["range_power"] // 2)) + st["kangaroos"] * 256 * 8
+
+
+def test_multi_rank_loop_on_one_gpu():
+    """solve_key_multi with world_size 1 (no torch.distributed): the same loop the ranks of a multi-GPU run execute,
+    on the real engine; the two-rank exchange itself is covered on the CPU (tests/test_solve_multi.py)."""
+    priv = (1 << 70) + 0xB3C1D2E7F0A1
+    pub = K.ec_mul_g(priv)
+    found, st = solve.solve_key_multi(1 << 70, (1 << 70) + (1 << 48) - 1, pub, grid=(16, 32), dp_bits=8, seed=3,
+                                      max_launches=2000)
+    assert found == priv and st["world"] == 1
+    assert st["jumps"] == st["kangaroos"] * 256 * st["launches"]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Known-key solve on one GPU (BASELINE configs 2/3 on a single device).
-Usage: python tools/solve_demo.py <range_bits> [dp_bits] [gx gy]"""
+"""Known-key solve (BASELINE configs 2/3).  One GPU: python tools/solve_demo.py <range_bits> [dp_bits] [gx gy]
+N GPUs of one node, one process per GPU, DP stream all-gathered and the DP table sharded over the ranks:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/solve_demo.py <range_bits> ..."""
 import os
 import sys
 import time
@@ -24,7 +25,13 @@ def progress(launches, n_dp, table):
 
 
 t0 = time.time()
-found, st = solve.solve_key(0, (1 << bits) - 1, pub, grid=grid, dp_bits=dp, seed=11, progress=progress)
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    found, st = solve.solve_key_multi(0, (1 << bits) - 1, pub, grid=grid, dp_bits=dp, seed=11, progress=progress)
+    if int(os.environ.get("RANK", "0")) != 0:
+        sys.exit(0 if found == priv else 1)
+    st["table"], st["dead"] = st["table_this_rank"], st["dead_this_rank"]
+else:
+    found, st = solve.solve_key(0, (1 << bits) - 1, pub, grid=grid, dp_bits=dp, seed=11, progress=progress)
 dt = time.time() - t0
 print(f"range 2^{bits}: key {'FOUND' if found == priv else 'NOT FOUND'} = {found:#x}" if found else "not found")
 print(f"  {st['device']}: kangaroos {st['kangaroos']}, DP bits {st['dp_bits']}, launches {st['launches']}, "
