@@ -71,14 +71,16 @@ def main():
     ap.add_argument("--nb-run", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=2048, help="kangaroos re-derived from their distance after the run")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="rehearsal of the N > 1 flow on a one-GPU box: gloo instead of RCCL, every rank on GPU 0")
     args = ap.parse_args()
 
     from kangaroo_amd import GPUEngine, dist, host
 
-    rank, local_rank, world = dist.init()
+    rank, local_rank, world = dist.init(backend="gloo" if args.rehearse_one_gpu else None)
     if world != args.gpus and world > 1:
         args.gpus = world
-    gpu_id = local_rank
+    gpu_id = 0 if args.rehearse_one_gpu else local_rank
 
     gx, gy = (int(v) for v in args.grid.split(",")) if args.grid else (0, 0)
     gx, gy = GPUEngine.GetGridSize(gpu_id, gx, gy)

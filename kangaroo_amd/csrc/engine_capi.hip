@@ -640,7 +640,9 @@ extern "C" int kg_kick(kg_engine *e) {
     const size_t ws_part = (size_t)WS_GROUPS * 3 * (size_t)e->K * (size_t)e->threads * sizeof(u32);
     if (ws_part >= (1ull << 32))
       return fail(KG_ERR_ARG, "GPUEngine: Kernel: herd too large for the streaming kernel's 4 GiB workspace (KG_MODE=reg lifts the limit)");
-    const size_t need = ws_part + (size_t)e->nb_run * (size_t)e->K * (size_t)e->threads;  // + jump-index history
+    // + jump-index history + pacing table (16-byte aligned behind the history)
+    const size_t hist_part = ((size_t)e->nb_run * (size_t)e->K * (size_t)e->threads + 15) & ~(size_t)15;
+    const size_t need = ws_part + hist_part + (size_t)PACE_KEYS * 4 * sizeof(u32);
     if (need > e->ws_bytes) {
       HIPCHK(hipStreamSynchronize(e->stream));
       if (e->ws) (void)hipFree(e->ws);
@@ -676,6 +678,11 @@ extern "C" int kg_kick(kg_engine *e) {
     sa.ws = e->ws;
     sa.hist = (unsigned char *)e->ws + (size_t)WS_GROUPS * 3 * (size_t)e->K * (size_t)e->threads * sizeof(u32);
     sa.K = (u32)e->K;
+    {
+      const size_t hist_part = ((size_t)e->nb_run * (size_t)e->K * (size_t)e->threads + 15) & ~(size_t)15;
+      sa.pace = (u32 *)(sa.hist + hist_part);
+      HIPCHK(hipMemsetAsync(sa.pace, 0, (size_t)PACE_KEYS * 4 * sizeof(u32), e->stream));
+    }
     hipLaunchKernelGGL(sv->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, sa);
     HIPCHK(hipGetLastError());
     // distances: D += sum over the launch's jump-index history (inside the timed region)

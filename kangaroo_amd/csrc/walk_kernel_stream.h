@@ -32,7 +32,9 @@ struct StreamArgs {
   u32 *ws;            // workspace, 9 * K rows of a.threads 12-byte entries
   unsigned char *hist;  // jump indices, [nb_run][K][a.threads]
   u32 K;              // kangaroos per lane
+  u32 *pace;          // [PACE_KEYS][4]: per physical CU {claim counter, pass of workgroup 0, pass of workgroup 1, -}, zeroed per launch
 };
+constexpr u32 PACE_KEYS = 4096;
 
 struct StreamRec {
   fe x, y;
@@ -115,7 +117,11 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     jt[row * JT_STRIDE + col] = a.jt->pxy[row][col];
   }
   for (u32 i = tid; i < NB_JUMP * DW; i += WALK_BLOCK) jdist[i] = a.jt->dist[i / DW][i % DW];
+  // physical CU of this workgroup: HW_ID (cu_id 11:8, sh_id 12, se_id 15:13) and XCC_ID; first come, first slot
+  const u32 pace_key = ((__builtin_amdgcn_s_getreg(0xF804) >> 8) & 0xFFu) | ((__builtin_amdgcn_s_getreg(0x1814) & 0xFu) << 8);
+  if (tid == 0) inv_ex[8 * 9 * 64] = atomicAdd(sa.pace + pace_key * 4, 1u) & 1u;
   __syncthreads();
+  const u32 pace_slot = inv_ex[8 * 9 * 64];
 
   const u32 Tl = blockIdx.x * WALK_BLOCK + tid;  // lane index < threads
   const u32 off = Tl * 12u;                      // byte offset inside a workspace row
@@ -282,6 +288,19 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   do {
     const bool asc = (run & 1) != 0;
     auto id_at = [&](u32 s) { return asc ? s : K - 1 - s; };
+    // Pacing.  The two workgroups resident on a CU do not share it evenly: the issue arbiter prefers the older
+    // wave, so the workgroup dispatched first used to finish at 70 % of the kernel time and its neighbour then ran
+    // alone at one wave per SIMD.  Every pass each workgroup publishes its pass number in a table indexed by the
+    // physical CU and raises its wave priority while it is behind its neighbour.
+    {
+      if (tid == 0) __hip_atomic_store(sa.pace + pace_key * 4 + 1 + pace_slot, run + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u32 other = __builtin_amdgcn_readfirstlane(
+          __hip_atomic_load(sa.pace + pace_key * 4 + 1 + (pace_slot ^ 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#ifndef KG_NO_PACE  // (A/B switch)
+      if (other > run + 1) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
+#endif
+    }
     // operands of the first pair: requested before the inversion, which hides the latency
     StreamRec A, B;
     fe QB;
@@ -438,7 +457,7 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_hist_sum_kernel(const unsigned 
 }
 
 constexpr size_t walk_stream_lds_bytes(int DW) {
-  return (size_t)(NB_JUMP * JT_STRIDE + NB_JUMP * DW + 8 * 9 * 64) * sizeof(u32);
+  return (size_t)(NB_JUMP * JT_STRIDE + NB_JUMP * DW + 8 * 9 * 64 + 4) * sizeof(u32);  // + the pacing slot
 }
 
 }  // namespace kg
