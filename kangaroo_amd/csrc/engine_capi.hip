@@ -375,7 +375,11 @@ extern "C" int kg_device_name(const kg_engine *e, char *buf, size_t buflen) {
 }
 extern "C" int kg_memory_bytes(const kg_engine *e, uint64_t *bytes) {
   if (!e || !bytes) return fail(KG_ERR_ARG, "kg_memory_bytes: bad argument");
-  *bytes = (u64)e->cap * 12 * sizeof(u64) + 2ull * e->max_found * sizeof(DpItemDev) + sizeof(JumpTableDev);
+  u64 b = (u64)e->cap * 12 * sizeof(u64) + 2ull * e->max_found * sizeof(DpItemDev) + sizeof(JumpTableDev);
+  if (e->streaming)  // the launch-time workspace of the streaming kernel: slots, jump-index history, pacing table
+    b += (u64)WS_GROUPS * 3 * (u64)e->K * (u64)e->threads * sizeof(u32) + (u64)e->nb_run * (u64)e->K * (u64)e->threads +
+         (u64)PACE_KEYS * 4 * sizeof(u32);
+  *bytes = b;
   return KG_OK;
 }
 extern "C" int kg_nb_thread(const kg_engine *e) { return e ? e->groups * e->per_group : 0; }
