@@ -23,6 +23,7 @@
 // the product only ever runs it inside the HIP kernels.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define KG_HD __host__ __device__ inline __attribute__((always_inline))
@@ -169,6 +170,81 @@ KG_HD u64 mad_u64_k(u32 a, u32 k, u64 acc) {
 #endif
 }
 
+template <int I, int N, typename F>
+KG_HD void fe_static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    fe_static_for<I + 1, N>(f);
+  }
+}
+// N multiply-adds into one accumulator as ONE asm statement.  The compiler pads every asm statement that defines a
+// VGPR with an s_nop before the next reader (it has to assume a dst_sel forwarding hazard), which is one s_nop
+// per multiply-add when each is a statement of its own.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KG_NO_MAD_CHAINS)
+#define KG_MAD_LINE(x, y) "v_mad_u64_u32 %0, %1, %" #x ", %" #y ", %0\n"
+template <int N>
+__device__ __forceinline__ u64 mad_chain(const u32 *a, const u32 *b, u64 acc);
+template <> __device__ __forceinline__ u64 mad_chain<1>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) : "+v"(acc), "=s"(c) : "v"(a[0]), "v"(b[0])); return acc;
+}
+template <> __device__ __forceinline__ u64 mad_chain<2>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) KG_MAD_LINE(4, 5) : "+v"(acc), "=s"(c) : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1])); return acc;
+}
+template <> __device__ __forceinline__ u64 mad_chain<3>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) KG_MAD_LINE(4, 5) KG_MAD_LINE(6, 7) : "+v"(acc), "=s"(c)
+             : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2])); return acc;
+}
+template <> __device__ __forceinline__ u64 mad_chain<4>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) KG_MAD_LINE(4, 5) KG_MAD_LINE(6, 7) KG_MAD_LINE(8, 9) : "+v"(acc), "=s"(c)
+             : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3])); return acc;
+}
+template <> __device__ __forceinline__ u64 mad_chain<5>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) KG_MAD_LINE(4, 5) KG_MAD_LINE(6, 7) KG_MAD_LINE(8, 9) KG_MAD_LINE(10, 11) : "+v"(acc), "=s"(c)
+             : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]), "v"(a[4]), "v"(b[4])); return acc;
+}
+template <> __device__ __forceinline__ u64 mad_chain<6>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) KG_MAD_LINE(4, 5) KG_MAD_LINE(6, 7) KG_MAD_LINE(8, 9) KG_MAD_LINE(10, 11) KG_MAD_LINE(12, 13)
+             : "+v"(acc), "=s"(c)
+             : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]), "v"(a[4]), "v"(b[4]),
+               "v"(a[5]), "v"(b[5])); return acc;
+}
+template <> __device__ __forceinline__ u64 mad_chain<7>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) KG_MAD_LINE(4, 5) KG_MAD_LINE(6, 7) KG_MAD_LINE(8, 9) KG_MAD_LINE(10, 11) KG_MAD_LINE(12, 13)
+             KG_MAD_LINE(14, 15) : "+v"(acc), "=s"(c)
+             : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]), "v"(a[4]), "v"(b[4]),
+               "v"(a[5]), "v"(b[5]), "v"(a[6]), "v"(b[6])); return acc;
+}
+template <> __device__ __forceinline__ u64 mad_chain<8>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) KG_MAD_LINE(4, 5) KG_MAD_LINE(6, 7) KG_MAD_LINE(8, 9) KG_MAD_LINE(10, 11) KG_MAD_LINE(12, 13)
+             KG_MAD_LINE(14, 15) KG_MAD_LINE(16, 17) : "+v"(acc), "=s"(c)
+             : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]), "v"(a[4]), "v"(b[4]),
+               "v"(a[5]), "v"(b[5]), "v"(a[6]), "v"(b[6]), "v"(a[7]), "v"(b[7])); return acc;
+}
+template <> __device__ __forceinline__ u64 mad_chain<9>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) KG_MAD_LINE(4, 5) KG_MAD_LINE(6, 7) KG_MAD_LINE(8, 9) KG_MAD_LINE(10, 11) KG_MAD_LINE(12, 13)
+             KG_MAD_LINE(14, 15) KG_MAD_LINE(16, 17) KG_MAD_LINE(18, 19) : "+v"(acc), "=s"(c)
+             : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]), "v"(a[4]), "v"(b[4]),
+               "v"(a[5]), "v"(b[5]), "v"(a[6]), "v"(b[6]), "v"(a[7]), "v"(b[7]), "v"(a[8]), "v"(b[8])); return acc;
+}
+#else
+template <int N>
+KG_HD u64 mad_chain(const u32 *a, const u32 *b, u64 acc) {
+  for (int i = 0; i < N; ++i) acc = mad_u64(a[i], b[i], acc);
+  return acc;
+}
+#endif
+// column k of a * b: sum of a[i] * b[k - i] over i in [LO, LO + N)
+template <int LO, int N>
+KG_HD u64 mad_column(const u32 *a, const u32 *b, int k, u64 acc) {
+  u32 ua[N], ub[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    ua[j] = a[LO + j];
+    ub[j] = b[k - LO - j];
+  }
+  return mad_chain<N>(ua, ub, acc);
+}
+
 KG_HD void fe_reduce_cols(fe &r, u32 (&t)[9], u64 t9acc) {
   // t: columns 0..8 carried to 29 bits with the fold of the high half applied;
   // t9acc (< 2^36, because wide limbs push up to 2^34 of carry out of column 8): weight 2^261.
@@ -195,25 +271,23 @@ KG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
   u32 h[9], t[9];
   u64 acc = 0;
   // columns 9..16 (weight 2^261 and up), carried into 29-bit limbs h[0..8]
-#pragma unroll
-  for (int k = 9; k <= 16; ++k) {
-#pragma unroll
-    for (int i = k - 8; i <= 8; ++i) acc = mad_u64(a.l[i], b.l[k - i], acc);
+  fe_static_for<9, 17>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    acc = mad_column<k - 8, 17 - k>(a.l, b.l, k, acc);
     h[k - 9] = (u32)acc & M29;
     acc >>= 29;
-  }
+  });
   h[8] = (u32)acc;
   // columns 0..8 plus h * (2^37 + 0x7A20)
   acc = 0;
-#pragma unroll
-  for (int k = 0; k <= 8; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) acc = mad_u64(a.l[i], b.l[k - i], acc);
+  fe_static_for<0, 9>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    acc = mad_column<0, k + 1>(a.l, b.l, k, acc);
     acc = mad_u64_k(h[k], FE_R0, acc);
     if (k > 0) acc = mad_u64_k(h[k - 1], FE_R1, acc);
     t[k] = (u32)acc & M29;
     acc >>= 29;
-  }
+  });
   acc = mad_u64_k(h[8], FE_R1, acc);
   fe_reduce_cols(r, t, acc);
 }
@@ -224,26 +298,35 @@ KG_HD void fe_sqr(fe &r, const fe &a) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) d[i] = a.l[i] << 1;
   u64 acc = 0;
+  // column k of a^2: 2 * a[i] * a[k - i] for 2 i < k, plus a[k/2]^2 when k is even, as one chain
+  auto sqr_column = [&](auto kc, u64 c) {
+    constexpr int k = decltype(kc)::value;
+    constexpr int lo = k > 8 ? k - 8 : 0, hi = (k + 1) / 2, n = hi - lo, m = n + ((k & 1) == 0 ? 1 : 0);
+    u32 ua[m], ub[m];
 #pragma unroll
-  for (int k = 9; k <= 16; ++k) {
-#pragma unroll
-    for (int i = k - 8; 2 * i < k; ++i) acc = mad_u64(d[i], a.l[k - i], acc);
-    if ((k & 1) == 0) acc = mad_u64(a.l[k / 2], a.l[k / 2], acc);
+    for (int j = 0; j < n; ++j) {
+      ua[j] = d[lo + j];
+      ub[j] = a.l[k - lo - j];
+    }
+    if ((k & 1) == 0) ua[m - 1] = ub[m - 1] = a.l[k / 2];
+    return mad_chain<m>(ua, ub, c);
+  };
+  fe_static_for<9, 17>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    acc = sqr_column(kc, acc);
     h[k - 9] = (u32)acc & M29;
     acc >>= 29;
-  }
+  });
   h[8] = (u32)acc;
   acc = 0;
-#pragma unroll
-  for (int k = 0; k <= 8; ++k) {
-#pragma unroll
-    for (int i = 0; 2 * i < k; ++i) acc = mad_u64(d[i], a.l[k - i], acc);
-    if ((k & 1) == 0) acc = mad_u64(a.l[k / 2], a.l[k / 2], acc);
+  fe_static_for<0, 9>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    acc = sqr_column(kc, acc);
     acc = mad_u64_k(h[k], FE_R0, acc);
     if (k > 0) acc = mad_u64_k(h[k - 1], FE_R1, acc);
     t[k] = (u32)acc & M29;
     acc >>= 29;
-  }
+  });
   acc = mad_u64_k(h[8], FE_R1, acc);
   fe_reduce_cols(r, t, acc);
 }
