@@ -226,6 +226,19 @@ template <> __device__ __forceinline__ u64 mad_chain<9>(const u32 *a, const u32 
              : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]), "v"(a[4]), "v"(b[4]),
                "v"(a[5]), "v"(b[5]), "v"(a[6]), "v"(b[6]), "v"(a[7]), "v"(b[7]), "v"(a[8]), "v"(b[8])); return acc;
 }
+template <> __device__ __forceinline__ u64 mad_chain<10>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) KG_MAD_LINE(4, 5) KG_MAD_LINE(6, 7) KG_MAD_LINE(8, 9) KG_MAD_LINE(10, 11) KG_MAD_LINE(12, 13)
+             KG_MAD_LINE(14, 15) KG_MAD_LINE(16, 17) KG_MAD_LINE(18, 19) KG_MAD_LINE(20, 21) : "+v"(acc), "=s"(c)
+             : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]), "v"(a[4]), "v"(b[4]),
+               "v"(a[5]), "v"(b[5]), "v"(a[6]), "v"(b[6]), "v"(a[7]), "v"(b[7]), "v"(a[8]), "v"(b[8]), "v"(a[9]), "v"(b[9])); return acc;
+}
+template <> __device__ __forceinline__ u64 mad_chain<11>(const u32 *a, const u32 *b, u64 acc) {
+  u64 c; asm(KG_MAD_LINE(2, 3) KG_MAD_LINE(4, 5) KG_MAD_LINE(6, 7) KG_MAD_LINE(8, 9) KG_MAD_LINE(10, 11) KG_MAD_LINE(12, 13)
+             KG_MAD_LINE(14, 15) KG_MAD_LINE(16, 17) KG_MAD_LINE(18, 19) KG_MAD_LINE(20, 21) KG_MAD_LINE(22, 23) : "+v"(acc), "=s"(c)
+             : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]), "v"(a[4]), "v"(b[4]),
+               "v"(a[5]), "v"(b[5]), "v"(a[6]), "v"(b[6]), "v"(a[7]), "v"(b[7]), "v"(a[8]), "v"(b[8]), "v"(a[9]), "v"(b[9]),
+               "v"(a[10]), "v"(b[10])); return acc;
+}
 #else
 template <int N>
 KG_HD u64 mad_chain(const u32 *a, const u32 *b, u64 acc) {
@@ -282,9 +295,20 @@ KG_HD void fe_mul(fe &r, const fe &a, const fe &b) {
   acc = 0;
   fe_static_for<0, 9>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    acc = mad_column<0, k + 1>(a.l, b.l, k, acc);
-    acc = mad_u64_k(h[k], FE_R0, acc);
-    if (k > 0) acc = mad_u64_k(h[k - 1], FE_R1, acc);
+    constexpr int m = k + 1 + (k > 0 ? 2 : 1);  // products of the column + the fold of h[k] (and h[k-1])
+    u32 ua[m], ub[m];
+#pragma unroll
+    for (int j = 0; j <= k; ++j) {
+      ua[j] = a.l[j];
+      ub[j] = b.l[k - j];
+    }
+    ua[k + 1] = h[k];
+    ub[k + 1] = FE_R0;
+    if (k > 0) {
+      ua[m - 1] = h[k - 1];
+      ub[m - 1] = FE_R1;
+    }
+    acc = mad_chain<m>(ua, ub, acc);
     t[k] = (u32)acc & M29;
     acc >>= 29;
   });
@@ -321,9 +345,21 @@ KG_HD void fe_sqr(fe &r, const fe &a) {
   acc = 0;
   fe_static_for<0, 9>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    acc = sqr_column(kc, acc);
-    acc = mad_u64_k(h[k], FE_R0, acc);
-    if (k > 0) acc = mad_u64_k(h[k - 1], FE_R1, acc);
+    constexpr int hi = (k + 1) / 2, sq = (k & 1) == 0 ? 1 : 0, m = hi + sq + (k > 0 ? 2 : 1);
+    u32 ua[m], ub[m];
+#pragma unroll
+    for (int j = 0; j < hi; ++j) {
+      ua[j] = d[j];
+      ub[j] = a.l[k - j];
+    }
+    if (sq) ua[hi] = ub[hi] = a.l[k / 2];
+    ua[hi + sq] = h[k];
+    ub[hi + sq] = FE_R0;
+    if (k > 0) {
+      ua[m - 1] = h[k - 1];
+      ub[m - 1] = FE_R1;
+    }
+    acc = mad_chain<m>(ua, ub, acc);
     t[k] = (u32)acc & M29;
     acc >>= 29;
   });
