@@ -7,9 +7,9 @@ HIPFLAGS ?= --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-
 CSRC     := kangaroo_amd/csrc
 BUILD    := build
 
-all: kangaroo_amd/libkangaroo_amd.so oracle
+all: kangaroo_amd/libkangaroo_amd.so oracle dropin_test
 
-$(BUILD)/engine_capi.o: $(CSRC)/engine_capi.hip $(CSRC)/walk_kernel.h $(CSRC)/walk_kernel_rot.h $(CSRC)/walk_kernel_stream.h $(CSRC)/herd_kernel.h $(CSRC)/fe29.h $(CSRC)/modinv30.h include/kangaroo_amd.h
+$(BUILD)/engine_capi.o: $(CSRC)/engine_capi.hip $(CSRC)/walk_common.h $(CSRC)/walk_kernel_rot.h $(CSRC)/walk_kernel_stream.h $(CSRC)/herd_kernel.h $(CSRC)/fe29.h $(CSRC)/modinv30.h include/kangaroo_amd.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/engine_capi.hip
 
@@ -23,6 +23,13 @@ kangaroo_amd/libkangaroo_amd.so: $(BUILD)/engine_capi.o $(BUILD)/host_secp.o
 oracle:
 	$(MAKE) -C oracle all
 
+# test-only: the C++ drop-in class compiled against stand-in headers and linked with a small driver, so that
+# tests/test_gpu_dropin.py can RUN it on the GPU box (the reference tree does not travel)
+dropin_test: tests/_build/dropin_host
+tests/_build/dropin_host: tests/dropin_host.cpp kangaroo_amd/dropin/GPUEngine_amd.cpp tests/dropin_stub/engine.h tests/dropin_stub/int.h tests/dropin_stub/constants.h include/kangaroo_amd.h kangaroo_amd/libkangaroo_amd.so
+	@mkdir -p tests/_build
+	$(CXX) -O2 -std=c++17 -Itests/dropin_stub -Iinclude -o $@ tests/dropin_host.cpp kangaroo_amd/dropin/GPUEngine_amd.cpp -Lkangaroo_amd -lkangaroo_amd -Wl,-rpath,'$$ORIGIN/../../kangaroo_amd'
+
 ref:
 	$(MAKE) -C oracle ref
 
@@ -30,4 +37,4 @@ clean:
 	rm -rf $(BUILD) kangaroo_amd/libkangaroo_amd.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle ref clean
+.PHONY: all oracle ref clean dropin_test

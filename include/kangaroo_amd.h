@@ -7,7 +7,7 @@
  * Int::bits64[0..3]); kangaroos are indexed in the reference's host order
  *     idx = block * (128 * threadsPerGroup) + g * threadsPerGroup + t,   type = idx % 2
  * (math/gpu/engine.cu:281-326, math/gpu/compute.h:58).  How the engine lays the herd out in
- * HBM is private.  kangaroo_amd/csrc/GPUEngine.cpp implements the C++ class on top of these
+ * HBM is private.  kangaroo_amd/dropin/GPUEngine_amd.cpp implements the C++ class on top of these
  * calls; INTEGRATION.md shows how the reference links against it.
  *
  * All functions return KG_OK (0) or a negative KG_ERR_* code; kg_last_error() gives the
@@ -58,6 +58,17 @@ int kg_default_grid(int gpu_id, int *x, int *y);
  * thread and allocates for 128 * groups * per_group kangaroos.  max_found is the caller's DP
  * capacity hint (core/kangaroo.cpp:408 passes 131072); the engine never allocates less. */
 int kg_create(int gpu_id, int groups, int per_group, uint32_t max_found, kg_engine **out);
+/* kg_create with explicit kernel tuning (the reference's counterpart is the compile-time choice of
+ * GPU_GRP_SIZE / -maxrregcount, constants.h:15 and Makefile:11-14; there is no runtime knob there).
+ * tune == NULL is kg_create.  Used by the parity tests and the throughput sweep to pin a kernel form. */
+#define KG_MODE_AUTO 0   /* streaming kernel; register-resident one for herds beyond its 4 GiB workspace */
+#define KG_MODE_STREAM 1 /* streaming kernel or KG_ERR_ARG */
+#define KG_MODE_REG 2    /* register-resident kernel (herd in VGPRs for the whole launch) */
+typedef struct {
+  int mode;       /* KG_MODE_* */
+  int k_per_lane; /* kangaroos per lane; 0 = engine's choice.  Streaming: even, 2..1024; register-resident: 16 */
+} kg_tuning;
+int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t max_found, const kg_tuning *tune, kg_engine **out);
 /* Replaces GPUEngine::~GPUEngine (math/gpu/engine.cu:172-181). */
 int kg_destroy(kg_engine *e);
 
@@ -127,6 +138,14 @@ int kg_kernel_info(const kg_engine *e, int *k_per_lane, int *delta_words, int *l
  * (template arguments: kangaroos per lane, window, delta words, waves per SIMD).  No counterpart in
  * the reference. */
 int kg_kernel_name(const kg_engine *e, char *buf, size_t buflen);
+
+/* Known-answer test of the DEVICE field arithmetic: n operations `op` (0 mul a*b, 1 sqr a^2, 2 sub a-b,
+ * 3 sub2 a-b-c, 4 (a-b)*c, 5 a mod p, 6 a^-1 (0 for 0), 7 ((a*b)*c)^2 through weak intermediates, 8 weak(a-b)*c) on
+ * operands of 8 little-endian 32-bit words each (any 256-bit value, also >= p); results canonical.  Operations 9
+ * and 10 take nine raw 29-bit limbs (a[0..7], b[0]) and run the settle + pack + unpack path of the streaming
+ * kernel's workspace format (fe_settle<0,1> / fe_settle<2,2>).  The GPU-side
+ * counterpart of the reference's Int::Check (math/cpu/int.cpp:1158-1511), which is CPU only. */
+int kg_field_kat(int gpu_id, int op, const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *r, uint32_t n);
 
 /* Replaces GPUEngine::AllocatePinnedMemory / FreePinnedMemory (engine.cu:221-233). */
 void *kg_alloc_pinned(size_t size);

@@ -21,10 +21,11 @@
 #include <vector>
 
 #include "../../include/kangaroo_amd.h"
-#include "walk_kernel.h"
+#include "walk_common.h"
 #include "walk_kernel_rot.h"
 #include "walk_kernel_stream.h"
 #include "herd_kernel.h"
+#include "kat_kernel.h"
 #include "../../include/kangaroo_amd_host.h"
 
 using namespace kg;
@@ -89,6 +90,7 @@ struct kg_engine {
   u32 threads = 0, grid = 0;
   int K = 0, DW = 0;
   bool streaming = false;     // streaming kernel (walk_kernel_stream.h) instead of the register-resident one
+  bool fell_back = false;     // streaming was wanted but the herd is beyond its 4 GiB workspace limit
   u32 *ws = nullptr;          // its workspace
   size_t ws_bytes = 0;
   u32 nb_run = KG_NB_RUN;
@@ -115,21 +117,17 @@ struct kg_engine {
 };
 
 // ---- kernel dispatch ------------------------------------------------------------------------
+// Shipped instantiations only: the streaming kernel (default) for 3- and 8-word distance sums, and the
+// register-resident kernel for herds beyond the streaming workspace limit (K = 16, one wave per SIMD).
+// Measurement variants live in tools/, not in the library.
 typedef void (*walk_fn)(WalkArgs);
 struct Variant {
-  int K, DW, W, U;  // U = 0: fully unrolled kernel; U > 0: rotating-window kernel with a window of U
+  int K, DW, W, U;  // kangaroos per lane, distance words, waves per SIMD, window of the rotating kernel
   walk_fn fn;
 };
-#define KG_VARIANT(K, DW, W) {K, DW, W, 0, kg_walk_kernel<K, DW, W>}
 #define KG_VARIANT_ROT(K, U, DW, W) {K, DW, W, U, kg_walk_kernel_rot<K, U, DW, W>}
 static const Variant g_variants[] = {
-    KG_VARIANT(1, 3, 2),  KG_VARIANT(1, 8, 2),  KG_VARIANT(4, 3, 2),  KG_VARIANT(4, 8, 2),
-    KG_VARIANT(8, 3, 2),  KG_VARIANT(8, 8, 2),  KG_VARIANT(8, 3, 1),  KG_VARIANT(8, 8, 1),
-    KG_VARIANT(12, 3, 1), KG_VARIANT(12, 8, 1),
-    KG_VARIANT_ROT(8, 4, 3, 2),  KG_VARIANT_ROT(8, 4, 8, 2),
-    KG_VARIANT_ROT(12, 4, 3, 1), KG_VARIANT_ROT(12, 4, 8, 1),
     KG_VARIANT_ROT(16, 4, 3, 1), KG_VARIANT_ROT(16, 4, 8, 1),
-    KG_VARIANT_ROT(16, 2, 3, 1), KG_VARIANT_ROT(16, 2, 8, 1),
 #ifdef KG_EXTRA_VARIANTS
     KG_EXTRA_VARIANTS
 #endif
@@ -140,44 +138,24 @@ struct StreamVariant {
   int DW, W;
   stream_fn fn;
 };
+#ifndef KG_STREAM_W
+#define KG_STREAM_W 2  // waves per SIMD the streaming kernel is compiled for
+#endif
 static const StreamVariant g_stream_variants[] = {
-    {3, 2, kg_walk_kernel_stream<3, 2>}, {8, 2, kg_walk_kernel_stream<8, 2>},
-    {3, 3, kg_walk_kernel_stream<3, 3>}, {8, 3, kg_walk_kernel_stream<8, 3>},
-    {3, 1, kg_walk_kernel_stream<3, 1>}, {8, 1, kg_walk_kernel_stream<8, 1>},
+    {3, KG_STREAM_W, kg_walk_kernel_stream<3, KG_STREAM_W>},
+    {8, KG_STREAM_W, kg_walk_kernel_stream<8, KG_STREAM_W>},
 };
 
-static int env_int(const char *name, int dflt) {
-  const char *s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
-
 static const Variant *find_variant(int K, int DW) {
-  const int w = env_int("KG_W", 0), u = env_int("KG_U", -1);
   for (const Variant &v : g_variants)
-    if (v.K == K && v.DW == DW && (w == 0 || v.W == w) && (u < 0 || v.U == u)) return &v;
+    if (v.K == K && v.DW == DW) return &v;
   return nullptr;
 }
 
 static const StreamVariant *find_stream_variant(int DW) {
-  const int w = env_int("KG_W", 2);
   for (const StreamVariant &v : g_stream_variants)
-    if (v.DW == DW && v.W == w) return &v;
+    if (v.DW == DW) return &v;
   return nullptr;
-}
-
-static bool stream_mode() {
-  // default: the streaming kernel (measured faster, profiles/r01_variants.txt); KG_MODE=reg selects the
-  // register-resident kernels
-  const char *m = getenv("KG_MODE");
-  return !(m && strcmp(m, "reg") == 0);
-}
-
-static int default_k() {
-  // KG_K / KG_U / KG_W are experiment knobs; the default (16 kangaroos per lane, window of 4,
-  // one wave per SIMD) is the measured best on MI355X (profiles/r01_variants.txt)
-  const int k = env_int("KG_K", 0);
-  if (k > 0 && (find_variant(k, 3) || find_variant(k, 8))) return k;
-  return 16;
 }
 
 static int bit_length256(const u64 v[4]) {
@@ -277,10 +255,16 @@ extern "C" int kg_destroy(kg_engine *e) {
   return KG_OK;
 }
 
-extern "C" int kg_create(int gpu_id, int groups, int per_group, uint32_t max_found, kg_engine **out) {
+extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t max_found, const kg_tuning *tune,
+                               kg_engine **out) {
   if (!out) return fail(KG_ERR_ARG, "kg_create: null out pointer");
   *out = nullptr;
   if (groups <= 0 || per_group <= 0) return fail(KG_ERR_ARG, "kg_create: grid must be positive");
+  const int want_mode = tune ? tune->mode : KG_MODE_AUTO;
+  const int want_k = tune ? tune->k_per_lane : 0;
+  if (want_mode != KG_MODE_AUTO && want_mode != KG_MODE_STREAM && want_mode != KG_MODE_REG)
+    return fail(KG_ERR_ARG, "kg_create: unknown kg_tuning.mode");
+  if (want_k < 0) return fail(KG_ERR_ARG, "kg_create: kg_tuning.k_per_lane must not be negative");
   int c = 0;
   if (kg_device_count(&c) != KG_OK) return KG_ERR_HIP;
   if (c == 0) return fail(KG_ERR_NODEVICE, "GPUEngine: There are no available device(s) that support HIP");
@@ -299,19 +283,35 @@ extern "C" int kg_create(int gpu_id, int groups, int per_group, uint32_t max_fou
   e->per_group = per_group;
   e->cus = prop.multiProcessorCount;
   e->n = (u64)KG_GROUP_SIZE * (u64)groups * (u64)per_group;
-  e->streaming = stream_mode();
-  // the streaming kernel addresses its workspace (108 B per kangaroo) through one 32-bit buffer descriptor:
-  // herds beyond 4 GiB of workspace (39 M kangaroos) run on the register-resident kernel
-  // (padding: at most 256 lanes x K <= 1024 kangaroos)
-  if (e->streaming && (e->n + 256 * 1024) * (u64)(WS_GROUPS * 12) >= (1ull << 32)) e->streaming = false;
+  e->streaming = want_mode != KG_MODE_REG;
   if (e->streaming) {
-    // K kangaroos per lane such that the herd fills about KG_W (2) waves per SIMD; KG_K overrides
-    const u64 lanes = (u64)e->cus * 4 * 64 * (u64)env_int("KG_W", 2);
-    u64 k = env_int("KG_K", 0) > 0 ? (u64)env_int("KG_K", 0) : (e->n + lanes - 1) / lanes;
-    e->K = (int)std::min<u64>(std::max<u64>(k, env_int("KG_K", 0) > 0 ? 2 : 4), 1024);
-    e->K += e->K & 1;  // the streaming kernel handles kangaroos in pairs
-  } else {
-    e->K = default_k();
+    // K kangaroos per lane such that the herd fills about two waves per SIMD (always even: the streaming kernel
+    // handles kangaroos in pairs)
+    const u64 lanes = (u64)e->cus * 4 * 64 * (u64)KG_STREAM_W;
+    u64 k = want_k > 0 ? (u64)want_k : std::max<u64>((e->n + lanes - 1) / lanes, 4);
+    k = std::min<u64>(std::max<u64>(k, 2), 1024);
+    k += k & 1;
+    // the streaming kernel addresses its workspace through ONE 32-bit buffer descriptor: with the padding this
+    // geometry implies it must stay below 4 GiB (about 39 M kangaroos); larger herds run on the register-resident
+    // kernel, 25 % slower, and kg_kernel_name says so
+    const u64 lanes_k = ((e->n + k - 1) / k + WALK_BLOCK - 1) / WALK_BLOCK * WALK_BLOCK;
+    if (lanes_k * k * (u64)(WS_SLOT_WORDS * 4) >= (1ull << 32)) {
+      if (want_mode == KG_MODE_STREAM) {
+        delete e;
+        return fail(KG_ERR_ARG, "kg_create: herd too large for the streaming kernel's 4 GiB workspace");
+      }
+      e->streaming = false;
+      e->fell_back = true;
+    } else {
+      e->K = (int)k;
+    }
+  }
+  if (!e->streaming) {
+    e->K = (want_k > 0 && !e->fell_back) ? want_k : 16;
+    if (!find_variant(e->K, 3)) {
+      delete e;
+      return fail(KG_ERR_ARG, "kg_create: the register-resident kernel is built for 16 kangaroos per lane");
+    }
   }
   e->DW = 3;
   const u64 per_lane = (e->n + e->K - 1) / e->K;
@@ -367,6 +367,10 @@ extern "C" int kg_create(int gpu_id, int groups, int per_group, uint32_t max_fou
   return KG_OK;
 }
 
+extern "C" int kg_create(int gpu_id, int groups, int per_group, uint32_t max_found, kg_engine **out) {
+  return kg_create_tuned(gpu_id, groups, per_group, max_found, nullptr, out);
+}
+
 // ---- accessors ----------------------------------------------------------------------------------------
 extern "C" int kg_device_name(const kg_engine *e, char *buf, size_t buflen) {
   if (!e || !buf || !buflen) return fail(KG_ERR_ARG, "kg_device_name: bad argument");
@@ -377,7 +381,7 @@ extern "C" int kg_memory_bytes(const kg_engine *e, uint64_t *bytes) {
   if (!e || !bytes) return fail(KG_ERR_ARG, "kg_memory_bytes: bad argument");
   u64 b = (u64)e->cap * 12 * sizeof(u64) + 2ull * e->max_found * sizeof(DpItemDev) + sizeof(JumpTableDev);
   if (e->streaming)  // the launch-time workspace of the streaming kernel: slots, jump-index history, pacing table
-    b += (u64)WS_GROUPS * 3 * (u64)e->K * (u64)e->threads * sizeof(u32) + (u64)e->nb_run * (u64)e->K * (u64)e->threads +
+    b += (u64)WS_SLOT_WORDS * (u64)e->K * (u64)e->threads * sizeof(u32) + (u64)e->nb_run * (u64)e->K * (u64)e->threads +
          (u64)PACE_KEYS * 4 * sizeof(u32);
   *bytes = b;
   return KG_OK;
@@ -630,32 +634,33 @@ extern "C" int kg_set_kangaroo(kg_engine *e, uint64_t k_idx, const uint64_t px[4
 }
 
 // ---- launch / collect ------------------------------------------------------------------------------------
-extern "C" int kg_kick(kg_engine *e) {
+// bytes of the streaming kernel's launch-time workspace: slots, jump-index history, pacing table
+static size_t stream_ws_part(const kg_engine *e) {
+  return (size_t)WS_SLOT_WORDS * (size_t)e->K * (size_t)e->threads * sizeof(u32);
+}
+static size_t stream_hist_part(const kg_engine *e) {  // 16-byte aligned: the pacing table sits behind it
+  return ((size_t)e->nb_run * (size_t)e->K * (size_t)e->threads + 15) & ~(size_t)15;
+}
+static size_t stream_ws_need(const kg_engine *e) {
+  return stream_ws_part(e) + stream_hist_part(e) + (size_t)PACE_KEYS * 4 * sizeof(u32);
+}
+
+static int kick_checks(kg_engine *e) {
   if (!e) return fail(KG_ERR_ARG, "kg_kick: null engine");
   if (!e->params_set || !e->herd_set) return fail(KG_ERR_STATE, "GPUEngine: Kernel: SetParams/SetKangaroos not called");
   if (e->inflight >= 0) return fail(KG_ERR_STATE, "GPUEngine: Kernel: a launch is already in flight");
   if (e->pending >= 0) return fail(KG_ERR_STATE, "GPUEngine: Kernel: previous launch not collected");
   if (bind(e) != KG_OK) return KG_ERR_HIP;
   e->DW = pick_delta_words(e);
+  return KG_OK;
+}
+
+// Queue one launch on the engine's stream.  ws: workspace of the streaming kernel (stream_ws_need bytes), unused
+// by the register-resident kernels.  Allocates nothing.
+static int launch_walk(kg_engine *e, void *ws) {
   const Variant *v = e->streaming ? nullptr : find_variant(e->K, e->DW);
   const StreamVariant *sv = e->streaming ? find_stream_variant(e->DW) : nullptr;
   if (!v && !sv) return fail(KG_ERR_STATE, "GPUEngine: Kernel: no kernel variant for this configuration");
-  if (sv) {
-    const size_t ws_part = (size_t)WS_GROUPS * 3 * (size_t)e->K * (size_t)e->threads * sizeof(u32);
-    if (ws_part >= (1ull << 32))
-      return fail(KG_ERR_ARG, "GPUEngine: Kernel: herd too large for the streaming kernel's 4 GiB workspace (KG_MODE=reg lifts the limit)");
-    // + jump-index history + pacing table (16-byte aligned behind the history)
-    const size_t hist_part = ((size_t)e->nb_run * (size_t)e->K * (size_t)e->threads + 15) & ~(size_t)15;
-    const size_t need = ws_part + hist_part + (size_t)PACE_KEYS * 4 * sizeof(u32);
-    if (need > e->ws_bytes) {
-      HIPCHK(hipStreamSynchronize(e->stream));
-      if (e->ws) (void)hipFree(e->ws);
-      e->ws = nullptr;
-      e->ws_bytes = 0;
-      HIPCHK(hipMalloc((void **)&e->ws, need));
-      e->ws_bytes = need;
-    }
-  }
   const int b = e->next_buf;
   WalkArgs a;
   a.X = e->X;
@@ -671,26 +676,25 @@ extern "C" int kg_kick(kg_engine *e) {
   a.out = e->out_dev[b];
   a.out_count = e->count_dev + b;
   a.max_found = e->max_found;
-  const size_t lds = sv ? walk_stream_lds_bytes(e->DW) : v->U ? walk_rot_lds_bytes(e->K, e->DW) : walk_lds_bytes(e->K, e->DW);
-  if (lds > 64 * 1024)  // above the default dynamic-LDS limit (gfx950 has 160 KiB per CU)
-    HIPCHK(hipFuncSetAttribute((const void *)v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = sv ? walk_stream_lds_bytes(e->DW) : walk_rot_lds_bytes(e->K, e->DW);
+  if (lds > 64 * 1024) {  // above the default dynamic-LDS limit (gfx950 has 160 KiB per CU)
+    const void *fn = sv ? (const void *)sv->fn : (const void *)v->fn;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   HIPCHK(hipMemsetAsync(e->count_dev + b, 0, sizeof(u32), e->stream));
   HIPCHK(hipEventRecord(e->ev_start[b], e->stream));
   if (sv) {
     StreamArgs sa;
     sa.a = a;
-    sa.ws = e->ws;
-    sa.hist = (unsigned char *)e->ws + (size_t)WS_GROUPS * 3 * (size_t)e->K * (size_t)e->threads * sizeof(u32);
+    sa.ws = (u32 *)ws;
+    sa.hist = (unsigned char *)ws + stream_ws_part(e);
     sa.K = (u32)e->K;
-    {
-      const size_t hist_part = ((size_t)e->nb_run * (size_t)e->K * (size_t)e->threads + 15) & ~(size_t)15;
-      sa.pace = (u32 *)(sa.hist + hist_part);
-      HIPCHK(hipMemsetAsync(sa.pace, 0, (size_t)PACE_KEYS * 4 * sizeof(u32), e->stream));
-    }
+    sa.pace = (u32 *)(sa.hist + stream_hist_part(e));
+    HIPCHK(hipMemsetAsync(sa.pace, 0, (size_t)PACE_KEYS * 4 * sizeof(u32), e->stream));
     hipLaunchKernelGGL(sv->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, sa);
     HIPCHK(hipGetLastError());
     // distances: D += sum over the launch's jump-index history (inside the timed region)
-    const u32 sum_grid = (u32)((e->cap + WALK_BLOCK - 1) / WALK_BLOCK);
+    const u32 sum_grid = (u32)((e->cap / 2 + WALK_BLOCK - 1) / WALK_BLOCK);  // one thread per pair of slots and lane
     if (e->DW == 3)
       hipLaunchKernelGGL(kg_hist_sum_kernel<3>, dim3(sum_grid), dim3(WALK_BLOCK), 0, e->stream, sa.hist, e->jt, e->D,
                          e->cap, e->n, e->threads, (u32)e->K, e->nb_run);
@@ -707,6 +711,23 @@ extern "C" int kg_kick(kg_engine *e) {
   e->inflight = b;
   e->next_buf = b ^ 1;
   return KG_OK;
+}
+
+extern "C" int kg_kick(kg_engine *e) {
+  const int rc = kick_checks(e);
+  if (rc != KG_OK) return rc;
+  if (e->streaming) {
+    const size_t need = stream_ws_need(e);  // grows with nb_run (kg_set_nb_run); kept between launches
+    if (need > e->ws_bytes) {
+      HIPCHK(hipStreamSynchronize(e->stream));
+      if (e->ws) (void)hipFree(e->ws);
+      e->ws = nullptr;
+      e->ws_bytes = 0;
+      HIPCHK(hipMalloc((void **)&e->ws, need));
+      e->ws_bytes = need;
+    }
+  }
+  return launch_walk(e, e->ws);
 }
 
 static int wait_launch(kg_engine *e, int b) {
@@ -801,10 +822,8 @@ extern "C" int kg_kernel_name(const kg_engine *e, char *buf, size_t buflen) {
   }
   const Variant *v = find_variant(e->K, dw);
   if (!v) return fail(KG_ERR_STATE, "kg_kernel_name: no kernel variant for this configuration");
-  if (v->U)
-    snprintf(buf, buflen, "kg_walk_kernel_rot<%d,%d,%d,%d>", v->K, v->U, v->DW, v->W);
-  else
-    snprintf(buf, buflen, "kg_walk_kernel<%d,%d,%d>", v->K, v->DW, v->W);
+  snprintf(buf, buflen, "kg_walk_kernel_rot<%d,%d,%d,%d>%s", v->K, v->U, v->DW, v->W,
+           e->fell_back ? " (fallback: herd beyond the streaming kernel's 4 GiB workspace)" : "");
   return KG_OK;
 }
 
@@ -813,9 +832,36 @@ extern "C" int kg_kernel_info(const kg_engine *e, int *k_per_lane, int *delta_wo
   const int dw = e->params_set ? pick_delta_words(e) : e->DW;
   if (k_per_lane) *k_per_lane = e->K;
   if (delta_words) *delta_words = dw;
-  const Variant *v = find_variant(e->K, dw);
-  if (lds_bytes)
-    *lds_bytes = (int)(e->streaming ? walk_stream_lds_bytes(dw) : (v && v->U) ? walk_rot_lds_bytes(e->K, dw) : walk_lds_bytes(e->K, dw));
+  if (lds_bytes) *lds_bytes = (int)(e->streaming ? walk_stream_lds_bytes(dw) : walk_rot_lds_bytes(e->K, dw));
   if (grid) *grid = (int)e->grid;
   return KG_OK;
+}
+
+// ---- on-device known-answer test of the field arithmetic -----------------------------------------------------
+extern "C" int kg_field_kat(int gpu_id, int op, const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *r,
+                            uint32_t n) {
+  if (!a || !b || !c || !r) return fail(KG_ERR_ARG, "kg_field_kat: null argument");
+  if (op < 0 || op >= KAT_NOPS) return fail(KG_ERR_ARG, "kg_field_kat: unknown operation");
+  if (n == 0) return KG_OK;
+  int cnt = 0;
+  if (kg_device_count(&cnt) != KG_OK) return KG_ERR_HIP;
+  if (cnt == 0) return fail(KG_ERR_NODEVICE, "GPUEngine: There are no available device(s) that support HIP");
+  if (gpu_id < 0 || gpu_id >= cnt) return fail(KG_ERR_ARG, "kg_field_kat: invalid gpuId");
+  HIPCHK(hipSetDevice(gpu_id));
+  const size_t bytes = (size_t)n * 8 * sizeof(u32);
+  u32 *dev = nullptr;
+  HIPCHK(hipMalloc((void **)&dev, 4 * bytes));
+  int rc = KG_OK;
+  hipError_t he = hipMemcpy(dev, a, bytes, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(dev + 8 * (size_t)n, b, bytes, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(dev + 16 * (size_t)n, c, bytes, hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(kg_kat_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, dev, dev + 8 * (size_t)n,
+                       dev + 16 * (size_t)n, dev + 24 * (size_t)n, n);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipMemcpy(r, dev + 24 * (size_t)n, bytes, hipMemcpyDeviceToHost);
+  if (he != hipSuccess) rc = fail(KG_ERR_HIP, std::string("kg_field_kat: ") + hipGetErrorString(he));
+  (void)hipFree(dev);
+  return rc;
 }

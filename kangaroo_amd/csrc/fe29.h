@@ -145,6 +145,22 @@ KG_HD void fe_canon(fe &r) {
   }
 }
 
+// ---- settle: weak -> fully carried 29-bit limbs with value < 2^256 (not necessarily < p), same residue --------------
+// For values whose excess over 29 bits sits in limbs FIRST..LAST only (fe_weak output: limbs 0 and 1; fe_mul / fe_sqr
+// output: limb 2).  Those limbs are carried; if the carry would run on past limb LAST + 1 (about once in 2^22 for a
+// product, far rarer for fe_weak output) the value is canonicalised instead.  The result can be packed into eight
+// 32-bit words with fe_to_words and comes back as a valid weak value with fe_from_words.
+template <int FIRST, int LAST>
+KG_HD void fe_settle(fe &r) {
+  static_assert(FIRST <= LAST && LAST < 7, "carry must end below limb 8");
+#pragma unroll
+  for (int i = FIRST; i <= LAST; ++i) {
+    r.l[i + 1] += r.l[i] >> 29;
+    r.l[i] &= M29;
+  }
+  if (__builtin_expect((r.l[LAST + 1] >> 29) != 0, 0)) fe_canon(r);
+}
+
 // ---- multiplication: a wide (limbs < 2^31.1, value < 2^259), b weak -> weak ----------------
 // acc + a * b, one v_mad_u64_u32.  Written as an asm statement on the device so that the column sums below
 // stay single accumulate chains that start from the carry of the previous column: left as C, the

@@ -11,7 +11,7 @@
 // the points live in a workspace in HBM: x, y as 9 limbs each [slot][18][lane] and the prefix products
 // [slot][9][lane].  Field arithmetic: fe29.h / modinv30.h, as in the jump kernels.
 #pragma once
-#include "walk_kernel.h"
+#include "walk_common.h"
 
 namespace kg {
 

@@ -1,12 +1,24 @@
-// modinv30.h — constant-time modular inverse mod p for gfx950 lanes.
+// modinv30.h — modular inverse mod p for gfx950 lanes, without divergence inside a wavefront.
 //
 // Replaces the reference's data-dependent 62-bit divstep loop (math/gpu/kernel.h:565-655,
-// math/cpu/intmod.cpp:153-292), which diverges across a wavefront, with the
-// Bernstein-Yang "safegcd" iteration in the fixed-length form: 20 batches of 30 divsteps on
-// signed 30-bit limbs (600 >= the 590 divsteps proven sufficient for 256-bit inputs with the
-// delta = 1/2 start).  Every lane executes the same instruction stream, so 64 different
-// inversions cost one wave-pass.  Output: canonical a^-1 in [0,p); 0 for a = 0 (mod p) —
-// the same contract as the reference's _ModInv / Int::ModInv.
+// math/cpu/intmod.cpp:153-292), which diverges across a wavefront, with the Bernstein-Yang "safegcd"
+// iteration on signed 30-bit limbs.  Three forms (fe_inv_t<MODE>):
+//   MODE 2 (the default, what the kernels run): batches of up to 30 divsteps, each batch KG_INV_NITER
+//     branch-free iterations (divsteps_30_fix); the wavefront loops until its slowest lane is done
+//     (about 21 batches), with a hard cap of KG_INV_MAX_BATCHES so that corrupted state can only give a
+//     wrong inverse (caught by the parity and invariant checks), never an endless loop;
+//   MODE 1: variable-time batches with a per-lane loop (divsteps_30_var);
+//   MODE 0: the fixed-length constant-time form, 20 batches of 30 divsteps (600 >= the 590 divsteps proven
+//     sufficient for 256-bit inputs with the delta = 1/2 start).
+// Every lane executes the same instruction stream, so 64 different inversions cost one wave-pass.
+// Output: canonical a^-1 in [0,p); 0 for a = 0 (mod p) — the same contract as the reference's
+// _ModInv / Int::ModInv.
+//
+// Credit: the limb layout, divsteps_30 / divsteps_30_var, the trans2x2 matrix, update_de_30 / update_fg_30
+// and normalize_30 follow the modinv32 implementation of bitcoin-core's libsecp256k1 (src/modinv32_impl.h,
+// MIT licence, Pieter Wuille et al.), itself an implementation of Bernstein & Yang, "Fast constant-time gcd
+// computation and modular inversion" (2019).  divsteps_30_fix, update_defg_30 and the SIMT loop are this
+// repository's own.
 #pragma once
 #include "fe29.h"
 
@@ -317,6 +329,12 @@ KG_HD void normalize_30(s30 &r, i32 sign) {
 #ifndef KG_INV_NITER
 #define KG_INV_NITER 8
 #endif
+// Batches the MODE 2 loop may run: the delta = 1 iteration needs at most 724 divsteps for 256-bit inputs
+// (25 full batches); every branch-free iteration consumes at least one bit, so a batch of 8 consumes at least 8
+// and usually all 30: about 21 batches in practice (tools/ubench_inv.hip), never more than 724 / 8 = 91.
+#ifndef KG_INV_MAX_BATCHES
+#define KG_INV_MAX_BATCHES 96
+#endif
 template <int MODE, int NITER = KG_INV_NITER>
 KG_HD void fe_inv_t(fe &r, const fe &a_in) {
   fe a = a_in;
@@ -339,7 +357,8 @@ KG_HD void fe_inv_t(fe &r, const fe &a_in) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) nz |= (u32)g.v[i];
 #pragma unroll 1
-    while (kg_any_lane(nz != 0)) {  // lanes that are done keep iterating harmlessly (g = 0 leaves d, f alone)
+    for (int batch = 0; batch < KG_INV_MAX_BATCHES && kg_any_lane(nz != 0); ++batch) {
+      // lanes that are done keep iterating harmlessly (g = 0 leaves d, f alone)
       trans2x2 t;
       zeta = divsteps_30_fix<NITER>(zeta, (u32)f.v[0], (u32)g.v[0], t);
       update_defg_30(d, e, f, g, t);

@@ -9,9 +9,9 @@
 // next step and stored as P[id].  Consecutive passes therefore run in opposite directions over the
 // kangaroo ids; the registers are reversed once per pass so that the window always sees them in order.
 //
-// Same arithmetic, same results as kg_walk_kernel (walk_kernel.h); see that file for the data layout.
+// See walk_common.h for the data layout.
 #pragma once
-#include "walk_kernel.h"
+#include "walk_common.h"
 
 namespace kg {
 

@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
 
 Item = namedtuple("Item", "x d kIdx")  # math/cpu/int.h:339-343
 
@@ -26,6 +27,12 @@ class KgError(RuntimeError):
 class _CItem(C.Structure):
     _fields_ = [("x", C.c_uint64 * 4), ("d", C.c_uint64 * 4), ("kIdx", C.c_uint64)]
 
+
+class _CTuning(C.Structure):
+    _fields_ = [("mode", C.c_int), ("k_per_lane", C.c_int)]
+
+
+MODE_AUTO, MODE_STREAM, MODE_REG = 0, 1, 2
 
 ITEM_DTYPE = np.dtype([("x", "<u8", (4,)), ("d", "<u8", (4,)), ("kIdx", "<u8")])
 assert ITEM_DTYPE.itemsize == C.sizeof(_CItem) == 72
@@ -53,6 +60,7 @@ def load_library():
         "kg_device_count": ([C.POINTER(C.c_int)], C.c_int),
         "kg_default_grid": ([C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "kg_create": ([C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(H)], C.c_int),
+        "kg_create_tuned": ([C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(_CTuning), C.POINTER(H)], C.c_int),
         "kg_destroy": ([H], C.c_int),
         "kg_device_name": ([H, C.c_char_p, C.c_size_t], C.c_int),
         "kg_memory_bytes": ([H, _u64p], C.c_int),
@@ -73,6 +81,7 @@ def load_library():
         "kg_last_kernel_ms": ([H, C.POINTER(C.c_float)], C.c_int),
         "kg_kernel_info": ([H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "kg_kernel_name": ([H, C.c_char_p, C.c_size_t], C.c_int),
+        "kg_field_kat": ([C.c_int, C.c_int, _u32p, _u32p, _u32p, _u32p, C.c_uint32], C.c_int),
         "kg_alloc_pinned": ([C.c_size_t], C.c_void_p),
         "kg_free_pinned": ([C.c_void_p], None),
         "kg_print_device_info": ([], C.c_int),
@@ -88,10 +97,10 @@ def load_library():
 
 
 ABI_SYMBOLS = [
-    "kg_device_count", "kg_default_grid", "kg_create", "kg_destroy", "kg_device_name", "kg_memory_bytes",
+    "kg_device_count", "kg_default_grid", "kg_create", "kg_create_tuned", "kg_destroy", "kg_device_name", "kg_memory_bytes",
     "kg_nb_thread", "kg_group_size", "kg_nb_kangaroo", "kg_set_wild_offset", "kg_set_params", "kg_set_kangaroos",
     "kg_get_kangaroos", "kg_herd_from_distances", "kg_set_kangaroo", "kg_set_nb_run", "kg_kick", "kg_collect", "kg_launch",
-    "kg_kick_and_wait", "kg_last_kernel_ms", "kg_kernel_info", "kg_kernel_name", "kg_alloc_pinned", "kg_free_pinned",
+    "kg_kick_and_wait", "kg_last_kernel_ms", "kg_kernel_info", "kg_kernel_name", "kg_field_kat", "kg_alloc_pinned", "kg_free_pinned",
     "kg_print_device_info", "kg_last_error", "kg_version",
 ]
 
@@ -121,10 +130,15 @@ def _limbs(v):
 class GPUEngine:
     """GPUEngine(nbThreadGroup, nbThreadPerGroup, gpuId, maxFound) — math/gpu/engine.cu:67-170."""
 
-    def __init__(self, nbThreadGroup, nbThreadPerGroup, gpuId, maxFound):
+    def __init__(self, nbThreadGroup, nbThreadPerGroup, gpuId, maxFound, mode=None, k_per_lane=0):
+        """mode / k_per_lane: kg_tuning (kg_create_tuned); mode is None, "stream" or "reg"."""
         self._L = load_library()
         self._h = C.c_void_p()
-        _chk(self._L.kg_create(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, C.byref(self._h)))
+        if mode is None and not k_per_lane:
+            _chk(self._L.kg_create(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, C.byref(self._h)))
+        else:
+            t = _CTuning({None: MODE_AUTO, "stream": MODE_STREAM, "reg": MODE_REG}[mode], int(k_per_lane or 0))
+            _chk(self._L.kg_create_tuned(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, C.byref(t), C.byref(self._h)))
         buf = C.create_string_buffer(256)
         _chk(self._L.kg_device_name(self._h, buf, 256))
         self.deviceName = buf.value.decode()
@@ -261,3 +275,35 @@ def items_to_tuples(items):
         d = sum(int(it["d"][i]) << (64 * i) for i in range(4))
         out.append(Item(x, d, int(it["kIdx"])))
     return out
+
+
+KAT_OPS = {"mul": 0, "sqr": 1, "sub": 2, "sub2": 3, "submul": 4, "canon": 5, "inv": 6, "weakmul": 7, "subweak": 8,
+           "settle01": 9, "settle2": 10}
+
+
+def field_kat_limbs(op, limbs, gpu_id=0):
+    """settle01 / settle2 on raw 29-bit limb vectors (lists of nine ints each); returns the canonical values."""
+    a = [sum(l[k] << (32 * k) for k in range(8)) for l in limbs]
+    b = [l[8] for l in limbs]
+    return field_kat(op, a, b, b, gpu_id)
+
+
+def field_kat(op, a, b=None, c=None, gpu_id=0):
+    """kg_field_kat: run the DEVICE field arithmetic on lists of Python ints (< 2^256); returns a list of ints."""
+    n = len(a)
+    b = a if b is None else b
+    c = a if c is None else c
+    assert len(b) == n and len(c) == n
+
+    def words(vs):
+        out = np.zeros((n, 8), dtype=np.uint32)
+        for i, v in enumerate(vs):
+            for k in range(8):
+                out[i, k] = (v >> (32 * k)) & 0xFFFFFFFF
+        return out
+
+    wa, wb, wc = words(a), words(b), words(c)
+    r = np.zeros((n, 8), dtype=np.uint32)
+    q = lambda x: x.ctypes.data_as(_u32p)
+    _chk(load_library().kg_field_kat(gpu_id, KAT_OPS[op], q(wa), q(wb), q(wc), q(r), n))
+    return [sum(int(r[i, k]) << (32 * k) for k in range(8)) for i in range(n)]

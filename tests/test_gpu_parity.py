@@ -11,17 +11,10 @@ from gpu_common import dp_multiset, make_case, oracle_dps
 pytestmark = pytest.mark.gpu
 
 
-def _engine(groups, per_group, case, nb_run=None, k=None, u=None, w=None, mode=None):
+def _engine(groups, per_group, case, nb_run=None, k=None, mode=None):
     from kangaroo_amd import GPUEngine
 
-    for name, val in (("KG_K", k), ("KG_U", u), ("KG_W", w), ("KG_MODE", mode)):
-        if val is not None:
-            os.environ[name] = str(val)
-    try:
-        e = GPUEngine(groups, per_group, 0, 65536 * 2)
-    finally:
-        for name in ("KG_K", "KG_U", "KG_W", "KG_MODE"):
-            os.environ.pop(name, None)
+    e = GPUEngine(groups, per_group, 0, 65536 * 2, mode=mode, k_per_lane=k or 0)  # kg_create_tuned
     e.SetWildOffset(case["width"] >> 1)  # core/kangaroo.cpp:436
     e.SetParams(case["dp_mask"], case["jd"], case["jx"], case["jy"])
     if nb_run:
@@ -30,20 +23,18 @@ def _engine(groups, per_group, case, nb_run=None, k=None, u=None, w=None, mode=N
     return e
 
 
-# register-resident kernels: (mode, kangaroos per lane, window U: 0 = fully unrolled kernel, waves/SIMD allowed)
-# streaming kernel: (mode, kangaroos per lane, -, waves/SIMD); 64 per lane leaves half of the only workgroup padding
-VARIANTS = [("reg", 1, 0, 2), ("reg", 4, 0, 2), ("reg", 8, 0, 2), ("reg", 8, 0, 1), ("reg", 12, 0, 1), ("reg", 8, 4, 2),
-            ("reg", 12, 4, 1), ("reg", 16, 4, 1), ("reg", 16, 2, 1),
-            ("stream", 2, None, 2), ("stream", 4, None, 2), ("stream", 6, None, 3), ("stream", 16, None, 2),
-            ("stream", 64, None, 2), ("stream", 10, None, 1)]
+# (kernel form, kangaroos per lane): the shipped register-resident instantiations and the streaming kernel at several
+# herd depths; 64 per lane leaves half of the only workgroup padding
+VARIANTS = [("reg", 16), ("stream", 2), ("stream", 4), ("stream", 6), ("stream", 10), ("stream", 16),
+            ("stream", 64)]
 
 
-@pytest.mark.parametrize("mode,k,u,w", VARIANTS)
-def test_dp_stream_and_state_match_oracle(mode, k, u, w):
+@pytest.mark.parametrize("mode,k", VARIANTS)
+def test_dp_stream_and_state_match_oracle(mode, k):
     """BASELINE config 2 in miniature: 64-bit range, same seed -> same DPs as the CPU walk.
     Odd and even step counts per launch exercise both pass directions of the fused pass."""
     case = make_case(64, 128 * 2 * 32, seed=1000 + k, dp_bits=6)
-    e = _engine(2, 32, case, nb_run=64, k=k, u=u, w=w, mode=mode)
+    e = _engine(2, 32, case, nb_run=64, k=k, mode=mode)
     assert e.KernelInfo()["k_per_lane"] == k
     assert ("stream" in e.KernelName()) == (mode == "stream")
     px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
@@ -67,7 +58,7 @@ def test_dp_stream_and_state_match_oracle(mode, k, u, w):
 
 
 @pytest.mark.parametrize("mode,groups,per_group,k", [("stream", 3, 7, None), ("stream", 1, 1, None), ("stream", 5, 3, 6),
-                                                     ("reg", 3, 7, 16), ("reg", 1, 1, 8)])
+                                                     ("reg", 3, 7, 16), ("reg", 1, 1, 16)])
 def test_ragged_herd_sizes(mode, groups, per_group, k):
     """Herds that do not fill the last workgroup (2688, 128, 1920 kangaroos): padding lanes walk a copy of
     kangaroo 0 and must never report; every real kangaroo matches the oracle."""
@@ -175,7 +166,6 @@ def test_two_engines_in_one_process_from_two_threads():
         e.close()
         results[tag] = ok
 
-    # engines are created one after the other (the KG_* knobs are process environment), then run together
     th = [threading.Thread(target=run, args=("a", 21, "stream")), threading.Thread(target=run, args=("b", 22, "stream"))]
     for t in th:
         t.start()
@@ -240,11 +230,7 @@ def test_512_workgroups_every_kangaroo_matches_oracle():
     workgroups 256 and up, which no herd of the other tests reaches."""
     from kangaroo_amd import GPUEngine, host
 
-    os.environ["KG_K"] = "2"
-    try:
-        e = GPUEngine(16, 128, 0, 1 << 16)
-    finally:
-        os.environ.pop("KG_K", None)
+    e = GPUEngine(16, 128, 0, 1 << 16, mode="stream", k_per_lane=2)
     n = e.nbKangaroo
     assert n == 262144 and e.KernelInfo()["grid"] == 512 and "stream" in e.KernelName()
     px, py, d = host.synthetic_herd(n)
