@@ -107,6 +107,23 @@ def all_gather_array(arr):
     return np.stack([o.cpu().numpy().view(np.uint64) for o in outs])
 
 
+def all_gather_varlen(arr):
+    """A uint64 array of ANY length from every rank -> the concatenation in rank order on every rank (the
+    same-herd collisions of one launch: usually none, no fixed bound)."""
+    rank, _, world = env_world()
+    arr = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+    if world == 1:
+        return arr.copy()
+    lens = all_gather_array(np.array([len(arr)], dtype=np.uint64))[:, 0].astype(np.int64)
+    longest = int(lens.max())
+    if longest == 0:
+        return arr[:0].copy()
+    buf = np.zeros(longest, dtype=np.uint64)
+    buf[: len(arr)] = arr
+    rows = all_gather_array(buf)
+    return np.concatenate([rows[r][: int(lens[r])] for r in range(world)])
+
+
 def all_gather_items(items):
     """The DP exchange: every rank's distinguished points of one launch (structured array, any length) ->
     the concatenation over ranks, in rank order, on every rank.

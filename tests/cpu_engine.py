@@ -33,6 +33,12 @@ class OracleEngine:
                 x, y = host.ec_add((host.to_int(self.px[i]), host.to_int(self.py[i])), key)
                 self.px[i], self.py[i] = host.limbs(x), host.limbs(y)
 
+    def SetKangaroos(self, px, py, d):
+        self.px, self.py, self.d = (np.ascontiguousarray(a, dtype=np.uint64).copy() for a in (px, py, d))
+
+    def GetKangaroos(self):
+        return self.px.copy(), self.py.copy(), self.d.copy()
+
     def SetKangaroo(self, k_idx, x, y, d):
         self.px[k_idx], self.py[k_idx], self.d[k_idx] = x, y, d
 
