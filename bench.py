@@ -23,15 +23,28 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 MAD32_PER_JUMP = 416          # 5 modmul * 74 + 1 modsqr * 46, inversion excluded
-# v_mad_u64_u32: 5.0 cycles per wave64 per SIMD measured (profiles/ubench_instr_table_r01.txt)
-# -> 1024 SIMDs * 64 lanes / 5.0 cycles * 2.4 GHz
-PEAK_MAD32_PER_S = 1024 * 64 / 5.0 * 2.4e9
+# v_mad_u64_u32: 5.08 cycles per wave64 per SIMD measured at 4 waves per SIMD (profiles/ubench_instr_table_r01.txt:96)
+# -> 1024 SIMDs * 64 lanes / 5.08 cycles * 2.4 GHz = 30.96 T MAD32/s
+MAD_CYCLES_PER_WAVE = 5.08
+PEAK_MAD32_PER_S = 1024 * 64 / MAD_CYCLES_PER_WAVE * 2.4e9
 STATE_BYTES_PER_KANGAROO = 192  # 96 B loaded + 96 B stored per launch
 
 
-def cpu_baseline(seconds_target=12.0):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seconds_target=10.0):
     """Oracle (CPU port of SolveKeyCPU's loop) on the host cores: 1024 kangaroos per thread as the
-    reference's CPU_GRP_SIZE, same 125-bit jump table.  Bounded sample; reported, never the target."""
+    reference's CPU_GRP_SIZE, same 125-bit jump table.  Bounded sample; reported, never the target.
+    Two figures as SURVEY §8d asks: all the threads the box gives one GPU (16) and one thread."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import kgoracle as K
 
@@ -43,8 +56,9 @@ def cpu_baseline(seconds_target=12.0):
     herds = [K.create_herd(rng, 125, width, key, 1024, 0) for _ in range(cores)]
     # calibrate on one thread
     t0 = time.time()
-    K.walk_raw(*herds[0], 20, 0xFFFFFFFF00000000, jd, jx, jy, 16)
-    per_step = (time.time() - t0) / 20
+    K.walk_raw(*herds[0], 60, 0xFFFFFFFF00000000, jd, jx, jy, 16)
+    per_step = (time.time() - t0) / 60
+    one_thread = 1024 / per_step
     steps = max(50, int(seconds_target / per_step))
 
     def work(h):
@@ -58,14 +72,63 @@ def cpu_baseline(seconds_target=12.0):
         t.join()
     dt = time.time() - t0
     jumps = cores * 1024 * steps
-    return {"value": jumps / dt, "unit": "jumps/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} threads x 1024 kangaroos x {steps} steps, 125-bit range, oracle/kg_oracle.c ({dt:.1f} s)"}
+    return {"value": jumps / dt, "unit": "jumps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "value_1thread": one_thread,
+            "sample": f"{cores} threads x 1024 kangaroos x {steps} steps, 125-bit range, oracle/kg_oracle.c ({dt:.1f} s); "
+                      f"1 thread: 1024 kangaroos x 60 steps"}
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, before
+    anything in this process has touched the GPU.  Rank 0's stdout (the JSON line) is relayed; the exit code is
+    non-zero if any rank failed."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in out.decode().splitlines():  # the JSON line to stdout, anything else a library printed to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def plumbing_only(args, rank, world):
+    """The N-rank flow without an engine: barrier, timed region, max over ranks, sum over ranks, one line."""
+    from kangaroo_amd import dist
+
+    gx, gy = (int(v) for v in args.grid.split(",")) if args.grid else (512, 128)
+    n = 128 * gx * gy
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + rank))  # ranks take different times: the slowest one must set the clock
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0)
+    total = dist.sum_over_ranks(n)
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing only (no GPU work, not a measurement)", "valid": False, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "value": total * args.nb_run * args.steps / elapsed,
+                          "jumps": total * args.nb_run * args.steps, "kangaroos_per_gpu": n, "elapsed_s": elapsed,
+                          "scaling": "weak"}), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=str, default="", help="x,y (kangaroos = 128*x*y per GPU); default engine grid")
     ap.add_argument("--nb-run", type=int, default=256)
@@ -73,14 +136,26 @@ def main():
     ap.add_argument("--check", type=int, default=2048, help="kangaroos re-derived from their distance after the run")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 flow on a one-GPU box: gloo instead of RCCL, every rank on GPU 0")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no GPU work at all: every rank reports the jumps its herd WOULD make (a CPU test of the rank "
+                         "launcher and the reductions; the line is marked invalid)")
     args = ap.parse_args()
 
-    from kangaroo_amd import GPUEngine, dist, host
+    # N > 1 without a launcher (no WORLD_SIZE in the environment): become the launcher
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
-    rank, local_rank, world = dist.init(backend="gloo" if args.rehearse_one_gpu else None)
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    from kangaroo_amd import dist
+
+    rank, local_rank, world = dist.init(backend="gloo" if (args.rehearse_one_gpu or args.plumbing_only) else None)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but {world} rank(s) were started", file=sys.stderr)
+        sys.exit(2)
     gpu_id = 0 if args.rehearse_one_gpu else local_rank
+    if args.plumbing_only:
+        return plumbing_only(args, rank, world)
+
+    from kangaroo_amd import GPUEngine, host
 
     gx, gy = (int(v) for v in args.grid.split(",")) if args.grid else (0, 0)
     gx, gy = GPUEngine.GetGridSize(gpu_id, gx, gy)
