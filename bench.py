@@ -195,15 +195,17 @@ def main():
 
     dist.barrier()
     torch.cuda.synchronize() if torch.cuda.is_available() else None
-    kernel_ms = []
+    kernel_ms, clock_mhz = [], []
     n_dp = 0
     t0 = time.perf_counter()
     eng.callKernel()
     for _ in range(args.steps - 1):
         n_dp += len(eng.Launch())
         kernel_ms.append(eng.LastKernelMs())
+        clock_mhz.append(eng.LastKernelClockMHz())
     n_dp += len(eng.Collect())
     kernel_ms.append(eng.LastKernelMs())
+    clock_mhz.append(eng.LastKernelClockMHz())
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -232,11 +234,15 @@ def main():
     avg_kernel_ms = float(np.mean(kernel_ms))
     kernel_jumps_per_s = n * args.nb_run / (avg_kernel_ms * 1e-3)
     achieved = kernel_jumps_per_s * MAD32_PER_JUMP
+    # the shader clock the kernel really ran at (s_memtime against the 100 MHz reference, workgroup 0): under this
+    # all-VALU load the chip settles well below its 2.4 GHz peak, so the issue-rate peak AT THAT CLOCK is quoted too
+    clk = float(np.median([c for c in clock_mhz if c > 0])) if any(c > 0 for c in clock_mhz) else None
+    peak_at_clk = 1024 * 64 / MAD_CYCLES_PER_WAVE * clk * 1e6 if clk else None
     # HBM bytes per launch from the PMC passes of the same command (FETCH_SIZE + WRITE_SIZE, see
     # profiles/r01_pmc_hbm.json and DESIGN.md "Measurement"); only quoted when the launch shape is the one profiled
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")) as f:
             pmc = json.load(f)
         if pmc["kangaroos_per_gpu"] == n and pmc["nb_run"] == args.nb_run and pmc["kernel"] == eng.KernelName():
             traffic = pmc["hbm_bytes_per_launch"]
@@ -247,10 +253,10 @@ def main():
     # register-resident kernels only load/store the herd once per launch.
     name = eng.KernelName()
     if "stream" in name:
-        # per jump: x, y read and written (72 + 72 B), one stored partial product per pair of kangaroos read and
-        # written (18 + 18 B), 1 B of jump-index history written and read back once by the epilogue; per
-        # launch the herd planes (192 B per kangaroo)
-        bytes_per_jump = 72 + 72 + 18 + 18 + 1 + 1 + STATE_BYTES_PER_KANGAROO / args.nb_run
+        # per jump: x, y read and written as eight words each (64 + 64 B), one stored partial product per pair of
+        # kangaroos read and written (16 + 16 B), 1 B of jump-index history written and read back once by
+        # kg_hist_sum_kernel; per launch the herd planes (192 B per kangaroo)
+        bytes_per_jump = 64 + 64 + 16 + 16 + 1 + 1 + STATE_BYTES_PER_KANGAROO / args.nb_run
     else:
         bytes_per_jump = STATE_BYTES_PER_KANGAROO / args.nb_run
     hbm_gbps = kernel_jumps_per_s * bytes_per_jump / 1e9
@@ -268,12 +274,16 @@ def main():
         "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MAD32_PER_S / 1e12,
                      "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_PER_S, "traffic": traffic,
                      "kernel": eng.KernelName(), "kernel_ms_avg": avg_kernel_ms,
+                     "kernel_ms_median": float(np.median(kernel_ms)),
+                     "shader_clock_mhz": clk, "peak_at_shader_clock": peak_at_clk / 1e12 if peak_at_clk else None,
+                     "frac_at_shader_clock": achieved / peak_at_clk if peak_at_clk else None,
                      "mad32_per_jump": MAD32_PER_JUMP, "kernel_jumps_per_s": kernel_jumps_per_s,
                      "hbm": {"bytes_per_jump": bytes_per_jump, "achieved_GBps": hbm_gbps, "peak_GBps": 8000.0,
                              "frac": hbm_gbps / 8000.0},
-                     "note": "primary bound per SURVEY §8d is VALU integer multiply issue (frac above); the streaming "
-                             "kernel also moves bytes_per_jump through HBM, see hbm.frac; traffic = PMC HBM bytes per "
-                             "launch (profiles/r01_pmc_hbm.json)"},
+                     "note": "primary bound per SURVEY §8d is VALU integer multiply issue: peak = 1024 SIMDs x 64 lanes / 5.08 "
+                             "cycles x 2.4 GHz (measured issue rate, nominal clock); frac_at_shader_clock uses the clock the "
+                             "kernel ran at.  The streaming kernel also moves bytes_per_jump through HBM, see hbm.frac; "
+                             "traffic = PMC HBM bytes per launch (profiles/)"},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

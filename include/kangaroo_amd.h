@@ -130,6 +130,10 @@ int kg_kick_and_wait(kg_engine *e);
 /* Duration in milliseconds of the last completed launch's kernel, measured with HIP events on the
  * engine's stream (bench.py's roofline figure).  No counterpart in the reference. */
 int kg_last_kernel_ms(const kg_engine *e, float *ms);
+/* Clock the last completed launch of the streaming kernel really ran at: shader clock cycles and ticks of the
+ * constant 100 MHz reference counter between the start and the end of workgroup 0 (s_memtime / s_memrealtime);
+ * MHz = 100 * cycles / ticks.  Zeros for the register-resident kernel.  No counterpart in the reference. */
+int kg_last_kernel_clock(const kg_engine *e, uint64_t *shader_cycles, uint64_t *ref_ticks_100mhz);
 /* Kernel variant in use: kangaroos per lane, distance-delta words, LDS bytes per workgroup,
  * workgroups launched.  No counterpart in the reference. */
 int kg_kernel_info(const kg_engine *e, int *k_per_lane, int *delta_words, int *lds_bytes, int *grid);

@@ -102,7 +102,7 @@ struct kg_engine {
   DpItemDev *out_host[2] = {nullptr, nullptr};
   DpItemDev *out_dev[2] = {nullptr, nullptr};
   u32 *count_dev = nullptr;   // [2]
-  u32 *count_host = nullptr;  // pinned [2]
+  u32 *count_host = nullptr;  // pinned [2] DP counters, then [2][4] clock stamps of the streaming kernel
   u64 *stage = nullptr;       // pinned staging for herd upload/download
   size_t stage_elems = 0;
   u64 wild[4] = {0, 0, 0, 0};
@@ -112,6 +112,7 @@ struct kg_engine {
   int inflight = -1, next_buf = 0;
   int pending = -1;  // completed by kick_and_wait, not yet collected
   float last_ms = 0.f;
+  u64 last_clk = 0, last_ref = 0;  // shader cycles and 100 MHz reference ticks of the last streaming launch (workgroup 0)
   int cus = 0;
   char name[256] = {0};
 };
@@ -352,7 +353,8 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
   CRT(hipMalloc((void **)&e->D, plane_bytes));
   CRT(hipMalloc((void **)&e->jt, sizeof(JumpTableDev)));
   CRT(hipMalloc((void **)&e->count_dev, 2 * sizeof(u32)));
-  CRT(hipHostMalloc((void **)&e->count_host, 2 * sizeof(u32), hipHostMallocDefault));
+  CRT(hipHostMalloc((void **)&e->count_host, (2 + 2 * PACE_TAIL) * sizeof(u32), hipHostMallocDefault));
+  memset(e->count_host, 0, (2 + 2 * PACE_TAIL) * sizeof(u32));
   for (int b = 0; b < 2; ++b) {
     CRT(hipHostMalloc((void **)&e->out_host[b], (size_t)e->max_found * sizeof(DpItemDev),
                       hipHostMallocMapped));
@@ -382,7 +384,7 @@ extern "C" int kg_memory_bytes(const kg_engine *e, uint64_t *bytes) {
   u64 b = (u64)e->cap * 12 * sizeof(u64) + 2ull * e->max_found * sizeof(DpItemDev) + sizeof(JumpTableDev);
   if (e->streaming)  // the launch-time workspace of the streaming kernel: slots, jump-index history, pacing table
     b += (u64)WS_SLOT_WORDS * (u64)e->K * (u64)e->threads * sizeof(u32) + (u64)e->nb_run * (u64)e->K * (u64)e->threads +
-         (u64)PACE_KEYS * 4 * sizeof(u32);
+         (u64)(PACE_KEYS * 4 + PACE_TAIL) * sizeof(u32);
   *bytes = b;
   return KG_OK;
 }
@@ -642,7 +644,7 @@ static size_t stream_hist_part(const kg_engine *e) {  // 16-byte aligned: the pa
   return ((size_t)e->nb_run * (size_t)e->K * (size_t)e->threads + 15) & ~(size_t)15;
 }
 static size_t stream_ws_need(const kg_engine *e) {
-  return stream_ws_part(e) + stream_hist_part(e) + (size_t)PACE_KEYS * 4 * sizeof(u32);
+  return stream_ws_part(e) + stream_hist_part(e) + (size_t)(PACE_KEYS * 4 + PACE_TAIL) * sizeof(u32);
 }
 
 static int kick_checks(kg_engine *e) {
@@ -690,7 +692,7 @@ static int launch_walk(kg_engine *e, void *ws) {
     sa.hist = (unsigned char *)ws + stream_ws_part(e);
     sa.K = (u32)e->K;
     sa.pace = (u32 *)(sa.hist + stream_hist_part(e));
-    HIPCHK(hipMemsetAsync(sa.pace, 0, (size_t)PACE_KEYS * 4 * sizeof(u32), e->stream));
+    HIPCHK(hipMemsetAsync(sa.pace, 0, (size_t)(PACE_KEYS * 4 + PACE_TAIL) * sizeof(u32), e->stream));
     hipLaunchKernelGGL(sv->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, sa);
     HIPCHK(hipGetLastError());
     // distances: D += sum over the launch's jump-index history (inside the timed region)
@@ -707,6 +709,9 @@ static int launch_walk(kg_engine *e, void *ws) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev_stop[b], e->stream));
   HIPCHK(hipMemcpyAsync(e->count_host + b, e->count_dev + b, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  if (sv)  // clock stamps written by workgroup 0 behind the pacing table
+    HIPCHK(hipMemcpyAsync(e->count_host + 2 + b * PACE_TAIL, (u32 *)((unsigned char *)ws + stream_ws_part(e) + stream_hist_part(e)) + PACE_KEYS * 4,
+                          PACE_TAIL * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipEventRecord(e->ev_done[b], e->stream));
   e->inflight = b;
   e->next_buf = b ^ 1;
@@ -734,6 +739,9 @@ static int wait_launch(kg_engine *e, int b) {
   HIPCHK(hipEventSynchronize(e->ev_done[b]));
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, e->ev_start[b], e->ev_stop[b]) == hipSuccess) e->last_ms = ms;
+  const u32 *st = e->count_host + 2 + b * PACE_TAIL;
+  e->last_clk = (u64)st[0] | ((u64)st[1] << 32);
+  e->last_ref = (u64)st[2] | ((u64)st[3] << 32);
   return KG_OK;
 }
 
@@ -808,6 +816,13 @@ extern "C" int kg_kick_and_wait(kg_engine *e) {
 extern "C" int kg_last_kernel_ms(const kg_engine *e, float *ms) {
   if (!e || !ms) return fail(KG_ERR_ARG, "kg_last_kernel_ms: bad argument");
   *ms = e->last_ms;
+  return KG_OK;
+}
+
+extern "C" int kg_last_kernel_clock(const kg_engine *e, uint64_t *shader_cycles, uint64_t *ref_ticks_100mhz) {
+  if (!e || !shader_cycles || !ref_ticks_100mhz) return fail(KG_ERR_ARG, "kg_last_kernel_clock: bad argument");
+  *shader_cycles = e->last_clk;
+  *ref_ticks_100mhz = e->last_ref;
   return KG_OK;
 }
 

@@ -34,9 +34,11 @@ struct StreamArgs {
   u32 *ws;            // workspace, 9 * K rows of a.threads 12-byte entries
   unsigned char *hist;  // jump indices, [nb_run][K][a.threads]
   u32 K;              // kangaroos per lane
-  u32 *pace;          // [PACE_KEYS][4]: per physical CU {claim counter, pass of workgroup 0, pass of workgroup 1, -}, zeroed per launch
+  u32 *pace;          // [PACE_KEYS][4]: per physical CU {claim counter, pass of workgroup 0, pass of workgroup 1, -}, zeroed per launch;
+                      // behind it PACE_TAIL words: the clock stamps of workgroup 0 (shader cycles, 100 MHz reference ticks)
 };
 constexpr u32 PACE_KEYS = 4096;
+constexpr u32 PACE_TAIL = 4;
 
 // Workspace access through a buffer descriptor: an offset outside the workspace is dropped by the hardware
 // bounds check instead of faulting, and there is no per-access address arithmetic on the VALU.
@@ -46,6 +48,11 @@ constexpr u32 PACE_KEYS = 4096;
 #endif
 #ifndef KG_WS_AUX_ST
 #define KG_WS_AUX_ST 0
+#endif
+// 1: kangaroos go in pairs and only the second of a pair stores the running product (one extra multiplication per
+// pair, 32 B less traffic per jump).  0: every kangaroo stores it (5 multiplications per jump instead of 5.5).
+#ifndef KG_WS_PAIRS
+#define KG_WS_PAIRS 1
 #endif
 typedef __amdgpu_buffer_rsrc_t ws_rsrc;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -128,6 +135,9 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   u32 *inv_ex = jdist + NB_JUMP * DW;      // [8][9][64]: products in, inverses out (shared inversion)
 
   const u32 tid = threadIdx.x;
+  // clock stamps (workgroup 0 reports them at the end): the shader clock counter against the constant 100 MHz
+  // reference gives the clock the kernel really ran at, which under this load is well below the 2.4 GHz peak
+  const u64 stamp_clk = __builtin_amdgcn_s_memtime(), stamp_ref = __builtin_amdgcn_s_memrealtime();
   for (u32 i = tid; i < NB_JUMP * 18; i += WALK_BLOCK) {
     u32 row = i / 18, col = i % 18;
     jt[row * JT_STRIDE + col] = a.jt->pxy[row][col];
@@ -191,7 +201,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     fe_mul(acc, dx, acc);
     ws_store<0>(wr, k, xw);
     ws_store<2>(wr, k, yw);
-    if (k & 1) {
+    if (!KG_WS_PAIRS || (k & 1)) {
       pk256 qw;
       fe_settle<2, 2>(acc);
       fe_pack(qw, acc);
@@ -304,6 +314,10 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     ws_load<0>(B.x, wr, id_at(1));
     ws_load<2>(B.y, wr, id_at(1));
     ws_load<4>(QB, wr, K > 2 ? id_at(2) : id_at(1));
+#if !KG_WS_PAIRS
+    pk256 QA;  // product of the dx still to come after A: what B's slot holds from the previous pass
+    ws_load<4>(QA, wr, id_at(1));
+#endif
     fe u;
     // One inversion for the four waves of the workgroup: lane l of every wave posts its product, the wave
     // whose turn it is inverts the product of the four and hands each wave the inverse of its own (3 + 6
@@ -363,6 +377,9 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       // queue is what waves block on), and fewer live registers
       StreamRec nA, nB;
       pk256 nQB;
+#if !KG_WS_PAIRS
+      pk256 nQA;
+#endif
       const u32 s2 = last ? s : s + 2;
       ws_load<0>(nA.x, wr, id_at(s2));
       ws_load<2>(nA.y, wr, id_at(s2));
@@ -382,6 +399,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       }
       fe_sub_wide(dxA, xA, jxA);
       fe_sub_wide(dxB, xB, jxB);
+#if KG_WS_PAIRS
       if (!last) {
         fe qA, qB;
         fe_unpack(qB, QB);
@@ -395,15 +413,34 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
         fe_mul(u, dxA, u);
         dxiB = u;
       }
+#else
+      {
+        fe qA;
+        fe_unpack(qA, QA);
+        fe_mul(dxiA, qA, u);
+        fe_mul(u, dxA, u);
+      }
+      if (!last) {
+        fe qB;
+        fe_unpack(qB, QB);
+        fe_mul(dxiB, qB, u);
+        fe_mul(u, dxB, u);
+      } else {  // nothing comes after B
+        dxiB = u;
+      }
+#endif
       {
         fe yA;
         fe_unpack(yA, A.y);
-        jump(xA, yA, dxiA, jxA, rowA, jmpA, idA, run, false);
+        jump(xA, yA, dxiA, jxA, rowA, jmpA, idA, run, !KG_WS_PAIRS);
       }
       __builtin_amdgcn_sched_barrier(0);
       ws_load<0>(nB.x, wr, id_at(s2 + 1));
       ws_load<2>(nB.y, wr, id_at(s2 + 1));
       ws_load<4>(nQB, wr, s2 + 2 < K ? id_at(s2 + 2) : id_at(s2 + 1));
+#if !KG_WS_PAIRS
+      ws_load<4>(nQA, wr, id_at(s2 + 1));
+#endif
       __builtin_amdgcn_sched_barrier(0);
       {
         fe yB;
@@ -413,6 +450,9 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       A = nA;
       B = nB;
       QB = nQB;
+#if !KG_WS_PAIRS
+      QA = nQA;
+#endif
     }
   } while (++run < a.nb_run);
 
@@ -429,6 +469,14 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     fe_canon(y);
     fe_pack(yw, y);
     pk_to_planes(a.Y, a.cap, p, yw);
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    const u64 dc = __builtin_amdgcn_s_memtime() - stamp_clk, dr = __builtin_amdgcn_s_memrealtime() - stamp_ref;
+    u32 *tail = sa.pace + PACE_KEYS * 4;
+    tail[0] = (u32)dc;
+    tail[1] = (u32)(dc >> 32);
+    tail[2] = (u32)dr;
+    tail[3] = (u32)(dr >> 32);
   }
 }
 

@@ -79,6 +79,7 @@ def load_library():
         "kg_launch": ([H, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)], C.c_int),
         "kg_kick_and_wait": ([H], C.c_int),
         "kg_last_kernel_ms": ([H, C.POINTER(C.c_float)], C.c_int),
+        "kg_last_kernel_clock": ([H, _u64p, _u64p], C.c_int),
         "kg_kernel_info": ([H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "kg_kernel_name": ([H, C.c_char_p, C.c_size_t], C.c_int),
         "kg_field_kat": ([C.c_int, C.c_int, _u32p, _u32p, _u32p, _u32p, C.c_uint32], C.c_int),
@@ -100,7 +101,7 @@ ABI_SYMBOLS = [
     "kg_device_count", "kg_default_grid", "kg_create", "kg_create_tuned", "kg_destroy", "kg_device_name", "kg_memory_bytes",
     "kg_nb_thread", "kg_group_size", "kg_nb_kangaroo", "kg_set_wild_offset", "kg_set_params", "kg_set_kangaroos",
     "kg_get_kangaroos", "kg_herd_from_distances", "kg_set_kangaroo", "kg_set_nb_run", "kg_kick", "kg_collect", "kg_launch",
-    "kg_kick_and_wait", "kg_last_kernel_ms", "kg_kernel_info", "kg_kernel_name", "kg_field_kat", "kg_alloc_pinned", "kg_free_pinned",
+    "kg_kick_and_wait", "kg_last_kernel_ms", "kg_last_kernel_clock", "kg_kernel_info", "kg_kernel_name", "kg_field_kat", "kg_alloc_pinned", "kg_free_pinned",
     "kg_print_device_info", "kg_last_error", "kg_version",
 ]
 
@@ -203,6 +204,12 @@ class GPUEngine:
         ms = C.c_float(0)
         _chk(self._L.kg_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def LastKernelClockMHz(self):
+        """Shader clock of the last streaming launch (kg_last_kernel_clock), 0.0 if unknown."""
+        c, r = C.c_uint64(0), C.c_uint64(0)
+        _chk(self._L.kg_last_kernel_clock(self._h, C.byref(c), C.byref(r)))
+        return 100.0 * c.value / r.value if r.value else 0.0
 
     # -- configuration
     def SetWildOffset(self, offset):
