@@ -116,6 +116,17 @@ int kg_set_nb_run(kg_engine *e, uint32_t nb_run);
 /* Replaces GPUEngine::callKernel (engine.cu:427-440): clear the DP counter and start one launch
  * of nb_run steps for every kangaroo, asynchronously. */
 int kg_kick(kg_engine *e);
+/* kg_kick for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same launch as kg_kick, but the streaming kernel's
+ * workspace (kangaroo slots, jump-index history, pacing table) is a static device array of
+ * KG_STATIC_WORKSPACE_BYTES inside the library instead of a buffer allocated at the first kg_kick; this call
+ * performs no hipMalloc / hipFree.  Returns KG_ERR_ARG if the engine's herd and step count need more than that
+ * (about 108 + nb_run bytes per kangaroo: 65 536 kangaroos at NB_RUN 256) or if the engine runs the
+ * register-resident kernel.  Pair it with kg_collect (kg_launch would queue an ordinary kg_kick).  All engines
+ * of one GPU share the array: launches made through this call must not overlap on one GPU (they would race);
+ * the array keeps the last launch's contents, what must start at zero is cleared per call. */
+#define KG_STATIC_WORKSPACE_BYTES (32u << 20)
+int kg_kick_static(kg_engine *e);
 /* First half of GPUEngine::Launch (engine.cu:486-537): wait for the launch in flight and copy out
  * its DPs.  *n receives the item count stored (<= cap).  If the launch produced more than the
  * engine's buffer or cap can hold, returns KG_ERR_LOST with *lost = number dropped. */

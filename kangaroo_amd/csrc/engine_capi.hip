@@ -227,6 +227,29 @@ extern "C" void kg_free_pinned(void *p) {
 extern "C" const char *kg_last_error(void) { return g_err.c_str(); }
 extern "C" const char *kg_version(void) { return "kangaroo_amd 0.1 (gfx950)"; }
 
+// ---- static workspace for kg_kick_static (the entry point that allocates nothing) -----------------------------
+// File-scope device array: every GPU the library runs on holds its own copy until the process ends.  In host code
+// the NAME of the array is only a stand-in (passing it to a kernel compiles and then faults on the GPU): the
+// device address is looked up once per device with hipGetSymbolAddress while that device is current (kg_create)
+// and only that pointer is used afterwards.
+static __device__ __align__(256) unsigned char scratch[KG_STATIC_WORKSPACE_BYTES];
+constexpr int KG_MAX_DEVICES = 64;
+static void *g_scratch_ptr[KG_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+// device must be current
+static int scratch_lookup(int gpu) {
+  if (gpu < 0 || gpu >= KG_MAX_DEVICES) return fail(KG_ERR_ARG, "GPUEngine: gpuId beyond the static workspace table");
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[gpu]) return KG_OK;
+  void *ptr = nullptr;
+  hipError_t he = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+  if (he != hipSuccess || !ptr)
+    return fail(KG_ERR_HIP, std::string("GPUEngine: hipGetSymbolAddress(scratch): ") + hipGetErrorString(he));
+  g_scratch_ptr[gpu] = ptr;
+  return KG_OK;
+}
+
 // ---- lifetime ---------------------------------------------------------------------------------------
 static int bind(const kg_engine *e) {
   HIPCHK(hipSetDevice(e->gpu));
@@ -277,6 +300,7 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(KG_ERR_NODEVICE, std::string("GPUEngine: device is ") + prop.gcnArchName +
                                      ", this engine is built for gfx950 only");
+  if (scratch_lookup(gpu_id) != KG_OK) return KG_ERR_HIP;
 
   kg_engine *e = new kg_engine();
   e->gpu = gpu_id;
@@ -733,6 +757,24 @@ extern "C" int kg_kick(kg_engine *e) {
     }
   }
   return launch_walk(e, e->ws);
+}
+
+// kg_kick for callers that cannot allocate: the streaming kernel's workspace is the library's static device
+// array instead of a hipMalloc'd buffer.  No hipMalloc / hipFree / allocating routine on this path.
+extern "C" int kg_kick_static(kg_engine *e) {
+  const int rc = kick_checks(e);
+  if (rc != KG_OK) return rc;
+  if (!e->streaming) return fail(KG_ERR_ARG, "kg_kick_static: the engine does not run the streaming kernel");
+  const size_t need = stream_ws_need(e);
+  if (need > (size_t)KG_STATIC_WORKSPACE_BYTES) {
+    char msg[200];
+    snprintf(msg, sizeof msg, "kg_kick_static: this herd and step count need %zu bytes of workspace, the static workspace holds %zu",
+             need, (size_t)KG_STATIC_WORKSPACE_BYTES);
+    return fail(KG_ERR_ARG, msg);
+  }
+  void *ws = (e->gpu >= 0 && e->gpu < KG_MAX_DEVICES) ? g_scratch_ptr[e->gpu] : nullptr;  // looked up in kg_create
+  if (!ws) return fail(KG_ERR_STATE, "kg_kick_static: static workspace address unknown for this device");
+  return launch_walk(e, ws);
 }
 
 static int wait_launch(kg_engine *e, int b) {

@@ -33,6 +33,7 @@ class _CTuning(C.Structure):
 
 
 MODE_AUTO, MODE_STREAM, MODE_REG = 0, 1, 2
+STATIC_WORKSPACE_BYTES = 32 << 20  # KG_STATIC_WORKSPACE_BYTES
 
 ITEM_DTYPE = np.dtype([("x", "<u8", (4,)), ("d", "<u8", (4,)), ("kIdx", "<u8")])
 assert ITEM_DTYPE.itemsize == C.sizeof(_CItem) == 72
@@ -75,6 +76,7 @@ def load_library():
         "kg_set_kangaroo": ([H, C.c_uint64, _u64p, _u64p, _u64p], C.c_int),
         "kg_set_nb_run": ([H, C.c_uint32], C.c_int),
         "kg_kick": ([H], C.c_int),
+        "kg_kick_static": ([H], C.c_int),
         "kg_collect": ([H, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)], C.c_int),
         "kg_launch": ([H, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)], C.c_int),
         "kg_kick_and_wait": ([H], C.c_int),
@@ -100,7 +102,7 @@ def load_library():
 ABI_SYMBOLS = [
     "kg_device_count", "kg_default_grid", "kg_create", "kg_create_tuned", "kg_destroy", "kg_device_name", "kg_memory_bytes",
     "kg_nb_thread", "kg_group_size", "kg_nb_kangaroo", "kg_set_wild_offset", "kg_set_params", "kg_set_kangaroos",
-    "kg_get_kangaroos", "kg_herd_from_distances", "kg_set_kangaroo", "kg_set_nb_run", "kg_kick", "kg_collect", "kg_launch",
+    "kg_get_kangaroos", "kg_herd_from_distances", "kg_set_kangaroo", "kg_set_nb_run", "kg_kick", "kg_kick_static", "kg_collect", "kg_launch",
     "kg_kick_and_wait", "kg_last_kernel_ms", "kg_last_kernel_clock", "kg_kernel_info", "kg_kernel_name", "kg_field_kat", "kg_alloc_pinned", "kg_free_pinned",
     "kg_print_device_info", "kg_last_error", "kg_version",
 ]
@@ -248,6 +250,11 @@ class GPUEngine:
     # -- launches
     def callKernel(self):
         _chk(self._L.kg_kick(self._h))
+        return True
+
+    def callKernelStatic(self):
+        """kg_kick_static: callKernel without any allocation (workspace in the library's static device array)."""
+        _chk(self._L.kg_kick_static(self._h))
         return True
 
     def callKernelAndWait(self):
