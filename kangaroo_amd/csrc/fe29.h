@@ -110,9 +110,8 @@ KG_HD void fe_weak(fe &r) {
 }
 
 // ---- full reduction to the canonical representative: any wide/weak -> canonical ----------
-KG_HD void fe_canon(fe &r) {
-  fe_weak(r);
-  // second carry pass (carries are 0/1 now)
+// the rare part: r has been through fe_weak; carries everything once more and handles bit 256 / values in [p, 2^256)
+KG_HD void fe_canon_rare(fe &r) {
   u32 c = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -121,11 +120,11 @@ KG_HD void fe_canon(fe &r) {
     c = t >> 29;
   }
   r.l[8] += c;
-  // v in [0, 2^256 + eps).  Two rare cases remain: bit 256 set, or v in [p, 2^256).
+  // v in [0, 2^256 + eps).  Two cases remain: bit 256 set, or v in [p, 2^256).
   u32 all = r.l[2] & r.l[3] & r.l[4] & r.l[5] & r.l[6] & r.l[7];
   bool top = (r.l[8] >> 24) != 0;
   bool maybe_ge_p = (all == M29) && (r.l[8] == 0xFFFFFFu) && (r.l[1] >= 0x1ffffff7u);
-  if (__builtin_expect(top || maybe_ge_p, 0)) {
+  if (top || maybe_ge_p) {
     // add K = 2^32 + 977; if that carries out of bit 256 then v >= p and v - p = v + K - 2^256
     fe t = r;
     t.l[0] += 977u;
@@ -143,6 +142,18 @@ KG_HD void fe_canon(fe &r) {
       r = t;  // v - p (v < 2p always holds here)
     }
   }
+}
+KG_HD void fe_canon(fe &r) {
+  fe_weak(r);
+  // now limbs 2..7 < 2^29 and limb 8 < 2^24; only limbs 0 and 1 can exceed 29 bits (by the fold of bit 256 and up).
+  // Carry those two; anything further (a carry running on into limb 3, or a value in [p, 2^256)) is the rare part.
+  r.l[1] += r.l[0] >> 29;
+  r.l[0] &= M29;
+  r.l[2] += r.l[1] >> 29;
+  r.l[1] &= M29;
+  const u32 all = r.l[2] & r.l[3] & r.l[4] & r.l[5] & r.l[6] & r.l[7];
+  const bool rare = (r.l[2] >> 29) != 0 || ((all == M29) && (r.l[8] == 0xFFFFFFu) && (r.l[1] >= 0x1ffffff7u));
+  if (__builtin_expect(rare, 0)) fe_canon_rare(r);
 }
 
 // ---- settle: weak -> fully carried 29-bit limbs with value < 2^256 (not necessarily < p), same residue --------------

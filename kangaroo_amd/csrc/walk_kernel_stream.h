@@ -372,22 +372,29 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     for (u32 s = 0; s < K; s += 2) {
       const u32 idA = id_at(s), idB = id_at(s + 1);
       const bool last = s + 2 >= K;
-      // prefetch the next pair (clamped at the end of the pass: valid slots, values unused).  A's successor is
-      // requested here, B's after A has jumped: two short bursts instead of one long one (the per-CU memory
-      // queue is what waves block on), and fewer live registers
-      StreamRec nA, nB;
-      pk256 nQB;
-#if !KG_WS_PAIRS
-      pk256 nQA;
-#endif
+      // The pair's packed operands were requested one iteration ago (the first pair's before the inversion).
+      // Each is unpacked where it is needed and its registers are then reloaded IN PLACE with the next pair's
+      // (clamped at the end of the pass: valid slots, values unused): no copies at the back edge, and the loads
+      // go out in three short bursts (x and product, y of A, y of B) instead of one long one — the per-CU
+      // memory queue is what waves block on.
       const u32 s2 = last ? s : s + 2;
-      ws_load<0>(nA.x, wr, id_at(s2));
-      ws_load<2>(nA.y, wr, id_at(s2));
-      __builtin_amdgcn_sched_barrier(0);
-
-      fe xA, xB;
+      fe xA, xB, qB;
       fe_unpack(xA, A.x);
       fe_unpack(xB, B.x);
+      fe_unpack(qB, QB);
+#if !KG_WS_PAIRS
+      fe qA;
+      fe_unpack(qA, QA);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      ws_load<0>(A.x, wr, id_at(s2));
+      ws_load<0>(B.x, wr, id_at(s2 + 1));
+      ws_load<4>(QB, wr, s2 + 2 < K ? id_at(s2 + 2) : id_at(s2 + 1));
+#if !KG_WS_PAIRS
+      ws_load<4>(QA, wr, id_at(s2 + 1));
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+
       const u32 jmpA = xA.l[0] & (NB_JUMP - 1), jmpB = xB.l[0] & (NB_JUMP - 1);
       hist_run[(u64)(idB >> 1) * threads] = (unsigned short)(asc ? (jmpA | (jmpB << 8)) : (jmpB | (jmpA << 8)));
       const u32 *rowA = jt + jmpA * JT_STRIDE, *rowB = jt + jmpB * JT_STRIDE;
@@ -401,8 +408,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       fe_sub_wide(dxB, xB, jxB);
 #if KG_WS_PAIRS
       if (!last) {
-        fe qA, qB;
-        fe_unpack(qB, QB);
+        fe qA;
         fe_mul(qA, dxB, qB);
         fe_mul(dxiA, qA, u);
         fe_mul(u, dxA, u);
@@ -414,15 +420,9 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
         dxiB = u;
       }
 #else
-      {
-        fe qA;
-        fe_unpack(qA, QA);
-        fe_mul(dxiA, qA, u);
-        fe_mul(u, dxA, u);
-      }
+      fe_mul(dxiA, qA, u);
+      fe_mul(u, dxA, u);
       if (!last) {
-        fe qB;
-        fe_unpack(qB, QB);
         fe_mul(dxiB, qB, u);
         fe_mul(u, dxB, u);
       } else {  // nothing comes after B
@@ -432,27 +432,19 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       {
         fe yA;
         fe_unpack(yA, A.y);
+        __builtin_amdgcn_sched_barrier(0);
+        ws_load<2>(A.y, wr, id_at(s2));
+        __builtin_amdgcn_sched_barrier(0);
         jump(xA, yA, dxiA, jxA, rowA, jmpA, idA, run, !KG_WS_PAIRS);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      ws_load<0>(nB.x, wr, id_at(s2 + 1));
-      ws_load<2>(nB.y, wr, id_at(s2 + 1));
-      ws_load<4>(nQB, wr, s2 + 2 < K ? id_at(s2 + 2) : id_at(s2 + 1));
-#if !KG_WS_PAIRS
-      ws_load<4>(nQA, wr, id_at(s2 + 1));
-#endif
-      __builtin_amdgcn_sched_barrier(0);
       {
         fe yB;
         fe_unpack(yB, B.y);
+        __builtin_amdgcn_sched_barrier(0);
+        ws_load<2>(B.y, wr, id_at(s2 + 1));
+        __builtin_amdgcn_sched_barrier(0);
         jump(xB, yB, dxiB, jxB, rowB, jmpB, idB, run, true);
       }
-      A = nA;
-      B = nB;
-      QB = nQB;
-#if !KG_WS_PAIRS
-      QA = nQA;
-#endif
     }
   } while (++run < a.nb_run);
 

@@ -71,3 +71,40 @@ def test_single_rank_runs_the_same_loop():
     key, st = solve.solve_key_multi(0, RANGE_END, pub, dp_bits=3, seed=5, nb_run=64, max_launches=400,
                                     engine_factory=lambda lr: OracleEngine(1024))
     assert key == PRIV and st["world"] == 1 and st["table_this_rank"] > 0
+
+
+FAIL_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path[:0] = [%r, %r, %r]
+    from kangaroo_amd import dist, host, solve
+    from cpu_engine import OracleEngine
+    rank, local_rank, world = dist.init(backend="gloo")
+
+    class Flaky(OracleEngine):
+        def Launch(self, spinWait=False):
+            if rank == 1 and self.launches == 2:
+                raise RuntimeError("engine failure injected on rank 1")
+            return super().Launch(spinWait)
+
+    pub = host.ec_mul_g(%d)
+    try:
+        solve.solve_key_multi(0, (1 << 60) - 1, pub, dp_bits=3, seed=5, nb_run=16, max_launches=50,
+                              engine_factory=lambda lr: Flaky(256))
+    except RuntimeError as ex:
+        print("RAISED " + str(ex), flush=True)
+        sys.exit(3)
+""") % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), PRIV)
+
+
+def test_failing_rank_stops_the_others_instead_of_hanging(tmp_path):
+    """A rank whose engine fails publishes that in the control exchange before raising; the other rank raises too
+    (it would otherwise wait for ever in the next all-gather)."""
+    script = tmp_path / "fail_worker.py"
+    script.write_text(FAIL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [3, 3], outs
+    assert "rank(s) [1] failed" in outs[0][0]
+    assert "engine failure injected on rank 1" in outs[1][0]

@@ -23,13 +23,15 @@ for f in glob.glob(root + "/pmc_*/**/*counter_collection.csv", recursive=True):
 kernel = max(vals["FETCH_SIZE"], key=lambda k: len(vals["FETCH_SIZE"][k]))
 fetch = sum(vals["FETCH_SIZE"][kernel]) / len(vals["FETCH_SIZE"][kernel])
 write = sum(vals["WRITE_SIZE"][kernel]) / len(vals["WRITE_SIZE"][kernel])
-per_jump = 72 + 72 + 18 + 18 + 1 + 1 + 192 / nb_run if "stream" in kernel else 192 / nb_run
+per_jump = 64 + 64 + 16 + 16 + 1 + 1 + 192 / nb_run if "stream" in kernel else 192 / nb_run
 print(json.dumps({
     "kangaroos_per_gpu": n, "nb_run": nb_run, "kernel": kernel, "launches_averaged": len(vals["FETCH_SIZE"][kernel]),
     "fetch_size_raw_kb": fetch, "write_size_raw_kb": write,
     "hbm_bytes_per_launch": 2 * fetch * 1024 + write * 1024,
     "algorithmic_bytes_per_launch": per_jump * n * nb_run,
-    "note": "read bytes = 2 x FETCH_SIZE (gfx950 correction for coalesced streaming reads; 12 B/lane dwordx3 buffer "
-            "loads, uncalibrated width), write bytes = WRITE_SIZE; kg_hist_sum_kernel's 1 B/jump read is a separate "
-            "kernel and not in these counters",
+    "note": "read bytes = 2 x FETCH_SIZE (gfx950 correction for coalesced streaming reads, 16 B per lane), write bytes = "
+            "WRITE_SIZE (exact for 16-byte-per-lane streaming stores); kg_hist_sum_kernel's 1 B/jump read is a separate "
+            "kernel and not in these counters; algorithmic = what the streaming design moves per jump (x, y as 32 B each "
+            "read and written, one 32 B partial product per pair of kangaroos read and written, 1 B of jump history) "
+            "plus the herd planes once per launch",
 }, indent=1))

@@ -34,5 +34,5 @@ if "SQ_LDS_BANK_CONFLICT" in avg:
     print(f"LDS bank-conflict cycles / LDS active      : {avg['SQ_LDS_BANK_CONFLICT'] / avg['SQ_LDS_IDX_ACTIVE']:.3f}")
 if "FETCH_SIZE" in avg:
     rd, wr = 2 * avg["FETCH_SIZE"] * 1024, avg["WRITE_SIZE"] * 1024
-    print(f"HBM read bytes per launch (2 x FETCH_SIZE) : {rd:.4g}   = {rd / jumps:.1f} B/jump (algorithmic 90 B/jump + 96 B/kangaroo)")
-    print(f"HBM write bytes per launch (WRITE_SIZE)    : {wr:.4g}   = {wr / jumps:.1f} B/jump (algorithmic 91 B/jump + 96 B/kangaroo)")
+    print(f"HBM read bytes per launch (2 x FETCH_SIZE) : {rd:.4g}   = {rd / jumps:.1f} B/jump (algorithmic 80 B/jump + 96 B/kangaroo)")
+    print(f"HBM write bytes per launch (WRITE_SIZE)    : {wr:.4g}   = {wr / jumps:.1f} B/jump (algorithmic 81 B/jump + 96 B/kangaroo)")
