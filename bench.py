@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--grid", type=str, default="", help="x,y (kangaroos = 128*x*y per GPU); default engine grid")
     ap.add_argument("--nb-run", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default=None, choices=["stream", "reg"],
+                    help="pin the kernel form (kg_create_tuned); default: the engine's choice (streaming)")
     ap.add_argument("--check", type=int, default=2048, help="kangaroos re-derived from their distance after the run")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 flow on a one-GPU box: gloo instead of RCCL, every rank on GPU 0")
@@ -159,7 +161,7 @@ def main():
 
     gx, gy = (int(v) for v in args.grid.split(",")) if args.grid else (0, 0)
     gx, gy = GPUEngine.GetGridSize(gpu_id, gx, gy)
-    eng = GPUEngine(gx, gy, gpu_id, 65536 * 2)
+    eng = GPUEngine(gx, gy, gpu_id, 65536 * 2, mode=args.mode)
     n = eng.nbKangaroo
 
     # configuration: built on rank 0, broadcast once (6 KiB jump table + dpMask + wild offset)

@@ -161,3 +161,26 @@ def test_72bit_solve_two_gpu_threads_one_table():
     assert found == priv and st["dp_bits"] == 12 and st["kangaroos"] == 1 << 23
     assert all(t["launches"] > 0 and t["dps"] > 0 for t in st["per_thread"])
     assert st["jumps"] < 64 * 2 * (1 << 36) + st["kangaroos"] * 256 * 8
+
+
+def test_config5_multi_key_low_dp_two_threads_with_saves(tmp_path):
+    """BASELINE config 5 in miniature, all at once: two keys in a row, DP = 8 (about one DP per kangaroo and launch),
+    two GPU threads feeding one table, and -w saves with the herds (GetKangaroos on both engines, table + 1 M
+    kangaroos on disk) while the search runs.  Nothing may be lost (a lost item raises), both keys must be found,
+    and the last work file must describe the last key."""
+    lo = 1 << 60
+    privs = [lo + 0x00C0FFEE12345678 % (1 << 56), lo + 0x00DEADBEEF987654 % (1 << 56)]
+    pubs = [K.ec_mul_g(p) for p in privs]
+    path = str(tmp_path / "c5.kg")
+    res = solve.solve_keys(lo, lo + (1 << 56) - 1, pubs, gpu_ids=(0, 0), grid=(32, 128), dp_bits=8, seed=31,
+                           work_file=path, save_period=0.0, max_launches=400)
+    assert [r[0] for r in res] == privs
+    for _, st in res:
+        assert st["saves"] >= 1 and st["kangaroos"] == 2 * 128 * 32 * 128
+        assert st["table"] + st["dead"] <= st["dps"] and st["table"] > 100000
+        assert all(t["launches"] > 0 for t in st["per_thread"])
+    info = host.work_info(path)
+    assert info["dp_bits"] == 8 and info["kangaroos"] == 2 * 128 * 32 * 128 and info["items"] > 100000
+    assert info["range_start"] == lo and info["range_end"] == lo + (1 << 56) - 1
+    sv = host.Solver(lo, lo + (1 << 56) - 1, pubs[1])
+    assert info["key"] == pubs[1] or info["key"] == sv.key  # the file carries the key as the reference writes it

@@ -1,14 +1,13 @@
 #!/usr/bin/env python3
 """Full-size invariant stress: after `launches` launches every sampled kangaroo must satisfy P = d*G (synthetic
 herd: tame-style points), and so must every DP of the last launch.  Host EC code of the product library.
-Usage: python tools/stress_invariant.py <gx> <gy> <launches> <kangaroos to check>   (env RANGE = range bits,
-KG_MODE / KG_K / KG_U / KG_W select the kernel)"""
+Usage: python tools/stress_invariant.py <gx> <gy> <launches> <kangaroos to check> [stream|reg]   (env RANGE = range bits)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from kangaroo_amd import GPUEngine, host
 gx_, gy_, launches, nchk = (int(v) for v in sys.argv[1:5])
-e = GPUEngine(gx_, gy_, 0, 1 << 17)
+e = GPUEngine(gx_, gy_, 0, 1 << 17, mode=sys.argv[5] if len(sys.argv) > 5 else None)
 n = e.nbKangaroo
 print(e.KernelName(), e.KernelInfo(), flush=True)
 px, py, d = host.synthetic_herd(n)
