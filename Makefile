@@ -26,7 +26,7 @@ oracle:
 # test-only: the C++ drop-in class compiled against stand-in headers and linked with a small driver, so that
 # tests/test_gpu_dropin.py can RUN it on the GPU box (the reference tree does not travel)
 dropin_test: tests/_build/dropin_host
-tests/_build/dropin_host: tests/dropin_host.cpp kangaroo_amd/dropin/GPUEngine_amd.cpp tests/dropin_stub/engine.h tests/dropin_stub/int.h tests/dropin_stub/constants.h include/kangaroo_amd.h kangaroo_amd/libkangaroo_amd.so
+tests/_build/dropin_host: tests/dropin_host.cpp kangaroo_amd/dropin/GPUEngine_amd.cpp tests/dropin_stub/engine.h tests/dropin_stub/gpuengine_standin.h tests/dropin_stub/int.h tests/dropin_stub/constants.h include/kangaroo_amd.h kangaroo_amd/libkangaroo_amd.so
 	@mkdir -p tests/_build
 	$(CXX) -O2 -std=c++17 -Itests/dropin_stub -Iinclude -o $@ tests/dropin_host.cpp kangaroo_amd/dropin/GPUEngine_amd.cpp -Lkangaroo_amd -lkangaroo_amd -Wl,-rpath,'$$ORIGIN/../../kangaroo_amd'
 
