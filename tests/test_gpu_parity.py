@@ -247,3 +247,26 @@ def test_512_workgroups_every_kangaroo_matches_oracle():
     ref = K.walk(px, py, d, 15, dp_mask, jd, jx, jy, cap=1 << 16)
     assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
     assert dp_multiset(items) == sorted((k, x, dd) for _, k, x, dd in ref)
+
+
+def test_nb_run_growth_and_arbitrary_dp_mask():
+    """kg_set_nb_run may grow between launches (the history part of the workspace is reallocated), and SetParams takes
+    any 64-bit mask on x.bits64[3] (the reference only ever builds top-bit masks, core/kangaroo.cpp:110-120): here a
+    mask with bits in both 32-bit halves."""
+    case = make_case(64, 128 * 1 * 64, seed=808, dp_bits=0)
+    case["dp_mask"] = 0x7000000030000000  # 5 bits: one DP in 32 jumps
+    e = _engine(1, 64, case, nb_run=8, mode="stream")
+    px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
+    e.callKernel()
+    assert dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 8)
+    e.SetNbRun(96)
+    e.callKernel()
+    got = dp_multiset(e.Launch())
+    ref = oracle_dps(case, px, py, d, 96)
+    assert got == ref and len(ref) > 10000
+    e.SetNbRun(200)  # takes effect with the launch after the one already queued
+    assert dp_multiset(e.Launch()) == oracle_dps(case, px, py, d, 96)
+    assert dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 200)
+    gx, gy, gd = e.GetKangaroos()
+    assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
+    e.close()
