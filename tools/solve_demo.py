@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Known-key solve (BASELINE configs 2/3).  One GPU: python tools/solve_demo.py <range_bits> [dp_bits] [gx gy]
+GPU_IDS=0,1,...: one host thread + engine per listed device on ONE shared table (the reference's shape; an id may repeat).
 N GPUs of one node, one process per GPU, DP stream all-gathered and the DP table sharded over the ranks:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/solve_demo.py <range_bits> ..."""
 import os
@@ -30,6 +31,9 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     if int(os.environ.get("RANK", "0")) != 0:
         sys.exit(0 if found == priv else 1)
     st["table"], st["dead"] = st["table_this_rank"], st["dead_this_rank"]
+elif os.environ.get("GPU_IDS"):
+    ids = tuple(int(v) for v in os.environ["GPU_IDS"].split(","))
+    found, st = solve.solve_key_threads(0, (1 << bits) - 1, pub, gpu_ids=ids, grid=grid, dp_bits=dp, seed=11, progress=progress)
 else:
     found, st = solve.solve_key(0, (1 << bits) - 1, pub, grid=grid, dp_bits=dp, seed=11, progress=progress)
 dt = time.time() - t0
