@@ -15,8 +15,9 @@
 // each a 256-bit value as eight fully carried 32-bit words (x canonical; y and P only < 2^256, see fe_settle);
 // row r of slot k is a run of `threads` 16-byte entries at row index k * 6 + r, so that one
 // buffer_load/store_dwordx4 moves 1024 contiguous, 16-byte aligned bytes per wavefront.  (Round 1 stored the nine
-// 29-bit limbs as they are, in dwordx3 rows: 182 B per jump instead of 161, and stores that straddle 64-byte
-// lines.)  Distances are not carried through the steps at all: every jump appends its jump index (one byte) to a
+// 29-bit limbs as they are, in dwordx3 rows: 183 B per jump instead of 162, and stores that straddle 64-byte
+// lines; both forms measure the same because the kernel runs at the board's power limit)
+// Distances are not carried through the steps at all: every jump appends its jump index (one byte) to a
 // history hist[step][pair][lane] (16 bits per pair of slots); kg_hist_sum_kernel adds the jump distances of every
 // kangaroo's history to D after the walk, and the few lanes that report a distinguished point sum their own history
 // up to that step.  The prologue copies the X/Y planes into the workspace, the epilogue copies back, so the
@@ -31,7 +32,7 @@ namespace kg {
 
 struct StreamArgs {
   WalkArgs a;
-  u32 *ws;            // workspace, 9 * K rows of a.threads 12-byte entries
+  u32 *ws;            // workspace, WS_ROWS * K rows of a.threads 16-byte entries
   unsigned char *hist;  // jump indices, [nb_run][K][a.threads]
   u32 K;              // kangaroos per lane
   u32 *pace;          // [PACE_KEYS][4]: per physical CU {claim counter, pass of workgroup 0, pass of workgroup 1, -}, zeroed per launch;
