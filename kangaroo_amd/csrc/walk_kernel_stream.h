@@ -43,12 +43,14 @@ constexpr u32 PACE_TAIL = 4;
 
 // Workspace access through a buffer descriptor: an offset outside the workspace is dropped by the hardware
 // bounds check instead of faulting, and there is no per-access address arithmetic on the VALU.
-// cache policy of the workspace accesses (aux operand of the buffer instructions: 1 = sc0, 2 = nt, 16 = sc1)
+// cache policy of the workspace accesses (aux operand of the buffer instructions: 1 = sc0, 2 = nt, 16 = sc1).
+// Stores are non-temporal: a slot is read again only a whole pass (hundreds of MB) later; measured +0.6 % on one box,
+// twice (nt loads: no gain, both: -0.5 %; gpurun_out/ab_r02c.txt summarised in profiles/r02_power_trace.txt).
 #ifndef KG_WS_AUX_LD
 #define KG_WS_AUX_LD 0
 #endif
 #ifndef KG_WS_AUX_ST
-#define KG_WS_AUX_ST 0
+#define KG_WS_AUX_ST 2
 #endif
 // 1: kangaroos go in pairs and only the second of a pair stores the running product (one extra multiplication per
 // pair, 32 B less traffic per jump).  0: every kangaroo stores it (5 multiplications per jump instead of 5.5).
