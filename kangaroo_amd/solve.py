@@ -155,11 +155,13 @@ def solve_key_threads(range_start, range_end, pub, gpu_ids=(0,), grid=(0, 0), dp
 
     n_per = [kangaroos_of(g) for g in gpu_ids]
     total = sum(n_per)
+    offset_count, offset_time, herds = 0, 0.0, [None] * len(gpu_ids)
+    info = host.work_info(resume_from) if resume_from else None
+    if dp_bits is None and info is not None:
+        dp_bits = info["dp_bits"]  # LoadWork: "if(initDPSize < 0) initDPSize = payload.dpSize" (storage/backup.cpp:110)
     if dp_bits is None:
         dp_bits = max(suggested_dp(sv.range_power, total), max(_ring_safe_dp(n, nb_run) for n in n_per))
-    offset_count, offset_time, herds = 0, 0.0, [None] * len(gpu_ids)
     if resume_from:
-        info = host.work_info(resume_from)
         offset_count, offset_time = info["total_count"], info["total_time"]
         px, py, d = sv.load_work(resume_from, total)
         got, pos = len(px), 0
