@@ -78,6 +78,54 @@ def cpu_baseline(seconds_target=10.0):
                       f"1 thread: 1024 kangaroos x 60 steps"}
 
 
+class PowerSampler:
+    """Board power of the first amdgpu hwmon device, sampled every 50 ms in a thread (read-only sysfs).  The jump
+    kernel runs at the board's power cap; the line reports what was drawn."""
+
+    def __init__(self):
+        import glob
+
+        self.path = self.cap = None
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            for leaf in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(d, leaf)):
+                    self.path = os.path.join(d, leaf)
+                    try:
+                        self.cap = int(open(os.path.join(d, "power1_cap")).read()) * 1e-6
+                    except (OSError, ValueError):
+                        pass
+                    break
+            if self.path:
+                break
+        self.samples = []
+        self._stop = threading.Event()
+        self._th = None
+
+    def start(self):
+        if not self.path:
+            return
+
+        def run():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append(int(open(self.path).read()) * 1e-6)
+                except (OSError, ValueError):
+                    pass
+                time.sleep(0.05)
+
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if self._th:
+            self._stop.set()
+            self._th.join()
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {"median_W": v[len(v) // 2], "max_W": v[-1], "cap_W": self.cap, "samples": len(v)}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, before
     anything in this process has touched the GPU.  Rank 0's stdout (the JSON line) is relayed; the exit code is
@@ -199,6 +247,9 @@ def main():
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     kernel_ms, clock_mhz = [], []
     n_dp = 0
+    power = PowerSampler() if world == 1 else None
+    if power:
+        power.start()
     t0 = time.perf_counter()
     eng.callKernel()
     for _ in range(args.steps - 1):
@@ -211,6 +262,7 @@ def main():
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     dist.barrier()
     elapsed = time.perf_counter() - t0
+    board_power = power.stop() if power else None
     elapsed = dist.max_over_ranks(elapsed)
     total_kangaroos = dist.sum_over_ranks(n)
 
@@ -279,6 +331,7 @@ def main():
                      "kernel_ms_median": float(np.median(kernel_ms)),
                      "shader_clock_mhz": clk, "peak_at_shader_clock": peak_at_clk / 1e12 if peak_at_clk else None,
                      "frac_at_shader_clock": achieved / peak_at_clk if peak_at_clk else None,
+                     "board_power": board_power,
                      "mad32_per_jump": MAD32_PER_JUMP, "kernel_jumps_per_s": kernel_jumps_per_s,
                      "hbm": {"bytes_per_jump": bytes_per_jump, "achieved_GBps": hbm_gbps, "peak_GBps": 8000.0,
                              "frac": hbm_gbps / 8000.0},
