@@ -601,43 +601,51 @@ struct Entry {
 // DPs with the same x, and those live in the same shard, so shards can be filled concurrently — by the worker
 // threads of one large batch and by the threads of several GPUs — while the per-x order of arrival is kept.
 constexpr int NSHARD = 256;
+constexpr u64 CELL_USED = 1ULL << 63;  // in Entry::d.v[3]: HashTable::Convert keeps only 62 bits of that limb
 struct Shard {
   std::mutex mu;
-  std::vector<Key128> keys;  // h stored +1 so that 0 marks an empty cell
-  std::vector<Entry> vals;
+  // One 64-byte cell per slot and nothing else (the reference's ENTRY is 64 bytes too, kangaroo.h:303-306): the key
+  // is read back from the entry — x limbs 0 and 1 and the bucket number h = x.limb2 & 0x3FFFF — and bit 63 of
+  // d.limb3 marks a used cell.
+  std::vector<Entry> cells;
   size_t used = 0;
+  static bool occupied(const Entry &c) { return (c.d.v[3] & CELL_USED) != 0; }
+  static Key128 key_of(const Entry &c) { return Key128{c.x.v[2] & 0x3FFFF, c.x.v[0], c.x.v[1]}; }
   void grow() {
-    const size_t ncap = keys.empty() ? 1024 : keys.size() * 2;
-    std::vector<Key128> nk(ncap, Key128{0, 0, 0});
-    std::vector<Entry> nv(ncap);
-    for (size_t i = 0; i < keys.size(); ++i)
-      if (keys[i].h) {
-        size_t j = Key128Hash()(keys[i]) & (ncap - 1);
-        while (nk[j].h) j = (j + 1) & (ncap - 1);
-        nk[j] = keys[i];
-        nv[j] = vals[i];
+    const size_t ncap = cells.empty() ? 1024 : cells.size() * 2;
+    std::vector<Entry> nc(ncap, Entry{U256{{0, 0, 0, 0}}, U256{{0, 0, 0, 0}}});
+    for (const Entry &c : cells)
+      if (occupied(c)) {
+        size_t j = Key128Hash()(key_of(c)) & (ncap - 1);
+        while (occupied(nc[j])) j = (j + 1) & (ncap - 1);
+        nc[j] = c;
       }
-    keys.swap(nk);
-    vals.swap(nv);
+    cells.swap(nc);
   }
-  // returns the cell of key (tagged), inserting e if absent; *existed tells which
-  Entry *find_or_insert(const Key128 &tagged, const Entry &e, bool *existed) {
-    if ((used + 1) * 5 > keys.size() * 3) grow();
-    size_t j = Key128Hash()(tagged) & (keys.size() - 1);
-    while (keys[j].h) {
-      if (keys[j] == tagged) {
+  // returns the cell of key, inserting e if absent; *existed tells which.  e.x must carry the key (key_of(e) == key).
+  Entry *find_or_insert(const Key128 &key, const Entry &e, bool *existed) {
+    if ((used + 1) * 5 > cells.size() * 3) grow();
+    size_t j = Key128Hash()(key) & (cells.size() - 1);
+    while (occupied(cells[j])) {
+      if (key_of(cells[j]) == key) {
         *existed = true;
-        return &vals[j];
+        return &cells[j];
       }
-      j = (j + 1) & (keys.size() - 1);
+      j = (j + 1) & (cells.size() - 1);
     }
-    keys[j] = tagged;
-    vals[j] = e;
+    cells[j] = e;
+    cells[j].d.v[3] |= CELL_USED;
     ++used;
     *existed = false;
-    return &vals[j];
+    return &cells[j];
   }
 };
+// the distance word of a cell without the bookkeeping bit
+static inline U256 cell_d(const Entry &c) {
+  U256 d = c.d;
+  d.v[3] &= ~CELL_USED;
+  return d;
+}
 
 struct kgh_solver {
   U256 range_start, range_end, width, width2;
@@ -712,19 +720,18 @@ static int shard_add(kgh_solver *s, const U256 &x, const U256 &d, u64 k_idx, U25
   Entry e;
   ht_convert(x, d, type, key, e);
   Shard &sh = s->shard[shard_of(key)];
-  Key128 tagged = key;
-  tagged.h += 1;
   std::lock_guard<std::mutex> lock(sh.mu);
   bool existed;
-  Entry *cell = sh.find_or_insert(tagged, e, &existed);
+  Entry *cell = sh.find_or_insert(key, e, &existed);
   if (!existed) return 1;
-  if (cmp(cell->d, e.d) == 0) {  // ADD_DUPLICATE -> treated as a dead kangaroo
+  const U256 stored = cell_d(*cell);
+  if (cmp(stored, e.d) == 0) {  // ADD_DUPLICATE -> treated as a dead kangaroo
     s->dead++;
     return 0;
   }
   U256 d0;
   uint32_t t0;
-  calc_dist_and_type(cell->d, d0, t0);
+  calc_dist_and_type(stored, d0, t0);
   if (t0 == type) {  // same herd
     s->dead++;
     return 0;
@@ -899,12 +906,13 @@ uint64_t kgh_solver_dead_count(const kgh_solver *s) { return s->dead; }
 uint64_t kgh_solver_dump(const kgh_solver *s, uint64_t *out, uint64_t cap) {
   uint64_t n = 0;
   for (const Shard &sh : s->shard)
-    for (size_t i = 0; i < sh.keys.size(); ++i) {
-      if (!sh.keys[i].h) continue;
+    for (const Entry &c : sh.cells) {
+      if (!Shard::occupied(c)) continue;
       if (n >= cap) return n;
-      out[9 * n] = sh.keys[i].h - 1;
-      memcpy(out + 9 * n + 1, sh.vals[i].x.v, 32);
-      memcpy(out + 9 * n + 5, sh.vals[i].d.v, 32);
+      const U256 d = cell_d(c);
+      out[9 * n] = Shard::key_of(c).h;
+      memcpy(out + 9 * n + 1, c.x.v, 32);
+      memcpy(out + 9 * n + 5, d.v, 32);
       ++n;
     }
   return n;
@@ -946,20 +954,20 @@ int kgh_work_save(const kgh_solver *s, const char *path, uint32_t dp_size, uint6
   // gather the shards into the reference's 2^18 buckets
   std::vector<uint32_t> cnt(HASH_BUCKETS + 1, 0);
   for (const Shard &sh : s->shard)
-    for (size_t i = 0; i < sh.keys.size(); ++i)
-      if (sh.keys[i].h) cnt[sh.keys[i].h - 1 + 1]++;
+    for (const Entry &c : sh.cells)
+      if (Shard::occupied(c)) cnt[Shard::key_of(c).h + 1]++;
   for (uint32_t h = 0; h < HASH_BUCKETS; ++h) cnt[h + 1] += cnt[h];
   std::vector<FileEntry> all(cnt[HASH_BUCKETS]);
   {
     std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
     for (const Shard &sh : s->shard)
-      for (size_t i = 0; i < sh.keys.size(); ++i)
-        if (sh.keys[i].h) {
-          FileEntry &e = all[pos[sh.keys[i].h - 1]++];
-          e.x[0] = sh.vals[i].x.v[0];
-          e.x[1] = sh.vals[i].x.v[1];
-          e.d[0] = sh.vals[i].d.v[0];
-          e.d[1] = sh.vals[i].d.v[1];
+      for (const Entry &c : sh.cells)
+        if (Shard::occupied(c)) {
+          FileEntry &e = all[pos[Shard::key_of(c).h]++];
+          e.x[0] = c.x.v[0];
+          e.x[1] = c.x.v[1];
+          e.d[0] = c.d.v[0];
+          e.d[1] = c.d.v[1];
         }
   }
   for (uint32_t h = 0; h < HASH_BUCKETS && ok; ++h) {
@@ -1034,9 +1042,9 @@ int kgh_work_load(kgh_solver *s, const char *path, uint64_t *px, uint64_t *py, u
     buf.resize(nb);
     ok = rd(f, buf.data(), (size_t)nb * sizeof(FileEntry));
     for (uint32_t i = 0; i < nb && ok; ++i) {
-      Key128 key{(u64)h + 1, buf[i].x[0], buf[i].x[1]};
+      Key128 key{(u64)h, buf[i].x[0], buf[i].x[1]};
       Entry e;
-      e.x = U256{{buf[i].x[0], buf[i].x[1], 0, 0}};
+      e.x = U256{{buf[i].x[0], buf[i].x[1], (u64)h, 0}};  // the file keeps 128 bits of x; limb 2 carries the bucket number
       e.d = U256{{buf[i].d[0], buf[i].d[1], 0, 0}};
       Shard &sh = s->shard[shard_of(key)];
       std::lock_guard<std::mutex> lock(sh.mu);
