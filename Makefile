@@ -9,7 +9,7 @@ BUILD    := build
 
 all: kangaroo_amd/libkangaroo_amd.so oracle dropin_test
 
-$(BUILD)/engine_capi.o: $(CSRC)/engine_capi.hip $(CSRC)/walk_common.h $(CSRC)/walk_kernel_rot.h $(CSRC)/walk_kernel_stream.h $(CSRC)/herd_kernel.h $(CSRC)/fe29.h $(CSRC)/modinv30.h include/kangaroo_amd.h
+$(BUILD)/engine_capi.o: $(CSRC)/engine_capi.hip $(CSRC)/walk_common.h $(CSRC)/walk_kernel_rot.h $(CSRC)/walk_kernel_stream.h $(CSRC)/herd_kernel.h $(CSRC)/kat_kernel.h $(CSRC)/fe29.h $(CSRC)/modinv30.h include/kangaroo_amd.h include/kangaroo_amd_host.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/engine_capi.hip
 

@@ -134,6 +134,7 @@ def launch_ranks(n, argv):
     import subprocess
 
     with socket.socket() as sk:
+        sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(n))
@@ -143,13 +144,31 @@ def launch_ranks(n, argv):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # rank 0's stdout is drained by a thread while ALL children are polled: a rank that dies early (GPU init failure,
+    # import error) must end the run with a clear message, not leave the others waiting in a rendezvous or a barrier
+    # until the distributed timeout
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    failed = False
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if not failed and any(rc not in (None, 0) for rc in rcs):
+            failed = True
+            for r, p in enumerate(procs):  # the survivors would wait for the dead rank: stop them (our own children)
+                if rcs[r] is None:
+                    p.terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out = b"".join(c for c in out_chunks if c)
     for line in out.decode().splitlines():  # the JSON line to stdout, anything else a library printed to stderr
-        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
+        print(line, file=sys.stdout if line.startswith("{") and not failed else sys.stderr, flush=True)
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        print(f"bench.py: ranks failed (rank, exit code; negative = stopped because another rank failed): {bad}", file=sys.stderr)
         return 1
     return 0
 

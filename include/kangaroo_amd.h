@@ -56,7 +56,10 @@ int kg_default_grid(int gpu_id, int *x, int *y);
 
 /* Replaces GPUEngine::GPUEngine (math/gpu/engine.cu:67-170): binds device gpu_id in the calling
  * thread and allocates for 128 * groups * per_group kangaroos.  max_found is the caller's DP
- * capacity hint (core/kangaroo.cpp:408 passes 131072); the engine never allocates less. */
+ * capacity hint (core/kangaroo.cpp:408 passes 131072); the engine never allocates less, and sizes its
+ * DP ring from the configuration: twice the items one launch is expected to report
+ * (kangaroos * nb_run / 2^dpBits), re-derived by kg_set_params / kg_set_nb_run, so that a default grid at
+ * DP = 8 loses nothing where the reference exits with "items lost" (engine.cu:99,506-510). */
 int kg_create(int gpu_id, int groups, int per_group, uint32_t max_found, kg_engine **out);
 /* kg_create with explicit kernel tuning (the reference's counterpart is the compile-time choice of
  * GPU_GRP_SIZE / -maxrregcount, constants.h:15 and Makefile:11-14; there is no runtime knob there).
@@ -67,6 +70,8 @@ int kg_create(int gpu_id, int groups, int per_group, uint32_t max_found, kg_engi
 typedef struct {
   int mode;       /* KG_MODE_* */
   int k_per_lane; /* kangaroos per lane; 0 = engine's choice.  Streaming: even, 2..1024; register-resident: 16 */
+  uint32_t ring_max_items; /* upper bound of the DP ring per launch in items (80 bytes of pinned host memory each, two
+                              buffers); 0 = the default, 2^25.  Never below the caller's max_found. */
 } kg_tuning;
 int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t max_found, const kg_tuning *tune, kg_engine **out);
 /* Replaces GPUEngine::~GPUEngine (math/gpu/engine.cu:172-181). */
@@ -116,13 +121,14 @@ int kg_set_nb_run(kg_engine *e, uint32_t nb_run);
 /* Replaces GPUEngine::callKernel (engine.cu:427-440): clear the DP counter and start one launch
  * of nb_run steps for every kangaroo, asynchronously. */
 int kg_kick(kg_engine *e);
-/* kg_kick for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc).  No counterpart in the reference.  Same launch as kg_kick, but the streaming kernel's
+/* kg_kick for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same launch as kg_kick, but the streaming kernel's
  * workspace (kangaroo slots, jump-index history, pacing table) is a static device array of
  * KG_STATIC_WORKSPACE_BYTES inside the library instead of a buffer allocated at the first kg_kick; this call
  * performs no hipMalloc / hipFree.  Returns KG_ERR_ARG if the engine's herd and step count need more than that
- * (about 108 + nb_run bytes per kangaroo: 65 536 kangaroos at NB_RUN 256) or if the engine runs the
- * register-resident kernel.  Pair it with kg_collect (kg_launch would queue an ordinary kg_kick).  All engines
+ * (slots 96 * S + history nb_run * S + DP chain heads 4 * S bytes for S = kangaroos rounded up to 256 lanes of an
+ * even number >= 4 per lane, + 64 KiB pacing table + 8 bytes per item of the DP ring: 65 536 kangaroos at NB_RUN
+ * 256) or if the engine runs the register-resident kernel, and KG_ERR_STATE if the DP ring would have to grow first
+ * (kg_set_params / kg_set_nb_run size it while no launch is in flight).  Pair it with kg_collect (kg_launch would queue an ordinary kg_kick).  All engines
  * of one GPU share the array: launches made through this call must not overlap on one GPU (they would race);
  * the array keeps the last launch's contents, what must start at zero is cleared per call. */
 #define KG_STATIC_WORKSPACE_BYTES (32u << 20)
@@ -134,6 +140,10 @@ int kg_collect(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *n, uint32_t
 /* GPUEngine::Launch (engine.cu:486-539): collect the launch in flight, start the next one. The
  * next launch is queued before the items are unpacked, so host work overlaps the GPU. */
 int kg_launch(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *n, uint32_t *lost);
+/* Items one launch can return: the capacity kg_collect / kg_launch need in `items` to take everything the DP ring
+ * holds under the current configuration (it follows kg_set_params / kg_set_nb_run).  The reference's counterpart is
+ * the maxFound the caller itself passed (engine.cu:99). */
+int kg_dp_capacity(const kg_engine *e, uint32_t *items);
 /* Replaces GPUEngine::callKernelAndWait (engine.cu:474-484): kick + wait, DPs stay queued for the
  * next kg_collect. */
 int kg_kick_and_wait(kg_engine *e);
@@ -150,7 +160,8 @@ int kg_last_kernel_clock(const kg_engine *e, uint64_t *shader_cycles, uint64_t *
 int kg_kernel_info(const kg_engine *e, int *k_per_lane, int *delta_words, int *lds_bytes, int *grid);
 
 /* Name of the kernel instantiation a launch will use, as it appears in a rocprofv3 kernel trace
- * (template arguments: kangaroos per lane, window, delta words, waves per SIMD).  No counterpart in
+ * (template arguments, register-resident kernel: kangaroos per lane, window, delta words, waves per SIMD;
+ * streaming kernel: waves per SIMD).  No counterpart in
  * the reference. */
 int kg_kernel_name(const kg_engine *e, char *buf, size_t buflen);
 

@@ -83,6 +83,9 @@ void kgh_solver_set_threads(kgh_solver *s, int threads);
 int kgh_solver_found(const kgh_solver *s, uint64_t priv[4]);
 uint64_t kgh_solver_table_size(const kgh_solver *s);
 uint64_t kgh_solver_dead_count(const kgh_solver *s);
+/* Items handed in that are neither in the table nor dead (the DP that solved the key, what arrived after it):
+ * table_size + dead_count + unstored_count == items handed in. */
+uint64_t kgh_solver_unstored_count(const kgh_solver *s);
 /* Dump the table as (h, X[4], D[4]) records of 9 uint64 each, HashTable::Convert layout
  * (memory/hashtable.cpp:65-89); returns the number written (<= cap). */
 uint64_t kgh_solver_dump(const kgh_solver *s, uint64_t *out, uint64_t cap);

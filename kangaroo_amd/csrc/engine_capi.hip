@@ -94,7 +94,9 @@ struct kg_engine {
   u32 *ws = nullptr;          // its workspace
   size_t ws_bytes = 0;
   u32 nb_run = KG_NB_RUN;
-  u32 max_found = 0;
+  u32 max_found = 0;          // the caller's hint (core/kangaroo.cpp:408), floor of the ring capacity
+  u32 ring_cap[2] = {0, 0};   // items each DP buffer holds
+  u32 ring_max = 0;           // upper bound of the ring (kg_tuning.ring_max_items or KG_RING_MAX)
   hipStream_t stream = nullptr;
   hipEvent_t ev_start[2] = {nullptr, nullptr}, ev_stop[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
   u64 *X = nullptr, *Y = nullptr, *D = nullptr;
@@ -134,28 +136,17 @@ static const Variant g_variants[] = {
 #endif
 };
 
+// The streaming kernel does not depend on the width of the distance sums: distances are summed from the jump-index
+// history by kg_hist_sum_kernel<DW> afterwards.
 typedef void (*stream_fn)(StreamArgs);
-struct StreamVariant {
-  int DW, W;
-  stream_fn fn;
-};
 #ifndef KG_STREAM_W
 #define KG_STREAM_W 2  // waves per SIMD the streaming kernel is compiled for
 #endif
-static const StreamVariant g_stream_variants[] = {
-    {3, KG_STREAM_W, kg_walk_kernel_stream<3, KG_STREAM_W>},
-    {8, KG_STREAM_W, kg_walk_kernel_stream<8, KG_STREAM_W>},
-};
+static const stream_fn g_stream_fn = kg_walk_kernel_stream<KG_STREAM_W>;
 
 static const Variant *find_variant(int K, int DW) {
   for (const Variant &v : g_variants)
     if (v.K == K && v.DW == DW) return &v;
-  return nullptr;
-}
-
-static const StreamVariant *find_stream_variant(int DW) {
-  for (const StreamVariant &v : g_stream_variants)
-    if (v.DW == DW) return &v;
   return nullptr;
 }
 
@@ -248,6 +239,75 @@ static int scratch_lookup(int gpu) {
     return fail(KG_ERR_HIP, std::string("GPUEngine: hipGetSymbolAddress(scratch): ") + hipGetErrorString(he));
   g_scratch_ptr[gpu] = ptr;
   return KG_OK;
+}
+
+// ---- DP ring ------------------------------------------------------------------------------------------
+// Two host-pinned buffers the kernels append distinguished points to.  The reference sizes its buffer from the
+// caller's maxFound alone and exits when a launch produces more (math/gpu/engine.cu:99,506-510; core/kangaroo.cpp:408
+// passes 131072, which a default grid overflows at once at DP = 8).  Here maxFound is a floor: the ring
+// holds twice what a launch is expected to report, n * nb_run / 2^dpBits, re-derived whenever the DP mask or the step
+// count changes, up to KG_RING_MAX items per buffer; only beyond that are items dropped and reported (KG_ERR_LOST).
+constexpr u32 KG_RING_MAX = 1u << 25;  // 33.5 M items = 2.7 GB of pinned memory per buffer
+
+static u32 ring_want(const kg_engine *e) {
+  const u64 floor_items = std::max<u64>(e->max_found, std::min<u64>(std::min<u64>(2 * e->n, 1u << 22), e->ring_max));
+  if (!e->params_set) return (u32)floor_items;
+  const int bits = __builtin_popcountll(e->dp_mask);
+  const long double expect = (long double)e->n * (long double)e->nb_run / (long double)(bits >= 64 ? 1.8446744073709552e19L : (long double)(1ull << bits));
+  const long double want = 2.0L * expect + 65536.0L;
+  const u64 ceil_items = std::max<u64>(e->ring_max, e->max_found);
+  const u64 w = want >= (long double)ceil_items ? ceil_items : (u64)want;
+  return (u32)std::min<u64>(std::max<u64>(floor_items, w), ceil_items);
+}
+
+// (re)allocate buffer b for `items` items; nothing may be using it
+static int ring_alloc(kg_engine *e, int b, u32 items) {
+  if (e->out_host[b]) {
+    HIPCHK(hipHostFree(e->out_host[b]));
+    e->out_host[b] = nullptr;
+    e->out_dev[b] = nullptr;
+    e->ring_cap[b] = 0;
+  }
+  HIPCHK(hipHostMalloc((void **)&e->out_host[b], (size_t)items * sizeof(DpItemDev), hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void **)&e->out_dev[b], e->out_host[b], 0));
+  e->ring_cap[b] = items;
+  return KG_OK;
+}
+
+// grow buffer b to what the current configuration needs (never shrinks).  The stream must not hold work on b.
+static int ring_ensure(kg_engine *e, int b) {
+  const u32 want = ring_want(e);
+  if (e->ring_cap[b] >= want) return KG_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return ring_alloc(e, b, want);
+}
+
+// after kg_set_params / kg_set_nb_run: grow both buffers now if no launch is in flight or waiting to be collected
+// (otherwise kg_kick grows the buffer it is about to use)
+static int ring_follow_config(kg_engine *e) {
+  if (e->inflight >= 0 || e->pending >= 0) return KG_OK;
+  for (int b = 0; b < 2; ++b) {
+    const int rc = ring_ensure(e, b);
+    if (rc != KG_OK) return rc;
+  }
+  return KG_OK;
+}
+
+// bytes of the streaming kernel's launch-time workspace: slots, jump-index history, pacing table (+ clock stamps),
+// then the DP chains: one head per kangaroo slot and one link per ring item (walk_kernel_stream.h)
+static size_t stream_ws_part(const kg_engine *e) {
+  return (size_t)WS_SLOT_WORDS * (size_t)e->K * (size_t)e->threads * sizeof(u32);
+}
+static size_t stream_hist_part(const kg_engine *e) {  // 16-byte aligned: the pacing table sits behind it
+  return ((size_t)e->nb_run * (size_t)e->K * (size_t)e->threads + 15) & ~(size_t)15;
+}
+static size_t stream_pace_part() { return (size_t)(PACE_KEYS * 4 + PACE_TAIL) * sizeof(u32); }  // a multiple of 16
+static size_t stream_head_part(const kg_engine *e) { return (size_t)e->cap * sizeof(u32); }     // cap is a multiple of 256
+static size_t stream_link_part(const kg_engine *e) {
+  return (size_t)std::max(e->ring_cap[0], e->ring_cap[1]) * sizeof(DpLink);
+}
+static size_t stream_ws_need(const kg_engine *e) {
+  return stream_ws_part(e) + stream_hist_part(e) + stream_pace_part() + stream_head_part(e) + stream_link_part(e);
 }
 
 // ---- lifetime ---------------------------------------------------------------------------------------
@@ -348,10 +408,9 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
   e->grid = (u32)blocks;
   e->threads = e->grid * WALK_BLOCK;
   e->cap = (u64)e->threads * e->K;
-  // the caller's maxFound is a hint (core/kangaroo.cpp:408); never smaller than it, and large
-  // enough for two DPs per kangaroo per launch up to 4M items so that low-DP runs (one DP per kangaroo and
-  // launch at DP = 8) do not drop items
-  e->max_found = std::max<u32>(max_found, (u32)std::min<u64>(2 * e->n, 1u << 22));
+  // the caller's maxFound is a hint (core/kangaroo.cpp:408) and the floor of the DP ring, see ring_want()
+  e->max_found = max_found;
+  e->ring_max = (tune && tune->ring_max_items) ? tune->ring_max_items : KG_RING_MAX;
   snprintf(e->name, sizeof e->name, "GPU #%d %s (%dx%d cores) Grid(%dx%d)", gpu_id,
            prop.name[0] ? prop.name : prop.gcnArchName,
            prop.multiProcessorCount, 64 * 4, groups, per_group);
@@ -380,9 +439,10 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
   CRT(hipHostMalloc((void **)&e->count_host, (2 + 2 * PACE_TAIL) * sizeof(u32), hipHostMallocDefault));
   memset(e->count_host, 0, (2 + 2 * PACE_TAIL) * sizeof(u32));
   for (int b = 0; b < 2; ++b) {
-    CRT(hipHostMalloc((void **)&e->out_host[b], (size_t)e->max_found * sizeof(DpItemDev),
-                      hipHostMallocMapped));
+    const u32 items = ring_want(e);
+    CRT(hipHostMalloc((void **)&e->out_host[b], (size_t)items * sizeof(DpItemDev), hipHostMallocMapped));
     CRT(hipHostGetDevicePointer((void **)&e->out_dev[b], e->out_host[b], 0));
+    e->ring_cap[b] = items;
   }
   e->stage_elems = (size_t)std::min<u64>(e->cap, 1u << 20);
   CRT(hipHostMalloc((void **)&e->stage, e->stage_elems * 12 * sizeof(u64), hipHostMallocDefault));
@@ -405,10 +465,8 @@ extern "C" int kg_device_name(const kg_engine *e, char *buf, size_t buflen) {
 }
 extern "C" int kg_memory_bytes(const kg_engine *e, uint64_t *bytes) {
   if (!e || !bytes) return fail(KG_ERR_ARG, "kg_memory_bytes: bad argument");
-  u64 b = (u64)e->cap * 12 * sizeof(u64) + 2ull * e->max_found * sizeof(DpItemDev) + sizeof(JumpTableDev);
-  if (e->streaming)  // the launch-time workspace of the streaming kernel: slots, jump-index history, pacing table
-    b += (u64)WS_SLOT_WORDS * (u64)e->K * (u64)e->threads * sizeof(u32) + (u64)e->nb_run * (u64)e->K * (u64)e->threads +
-         (u64)(PACE_KEYS * 4 + PACE_TAIL) * sizeof(u32);
+  u64 b = (u64)e->cap * 12 * sizeof(u64) + ((u64)e->ring_cap[0] + e->ring_cap[1]) * sizeof(DpItemDev) + sizeof(JumpTableDev);
+  if (e->streaming) b += stream_ws_need(e);  // slots, jump-index history, pacing table, DP chains
   *bytes = b;
   return KG_OK;
 }
@@ -425,7 +483,8 @@ extern "C" int kg_set_wild_offset(kg_engine *e, const uint64_t offset[4]) {
 extern "C" int kg_set_nb_run(kg_engine *e, uint32_t nb_run) {
   if (!e || nb_run == 0) return fail(KG_ERR_ARG, "kg_set_nb_run: bad argument");
   e->nb_run = nb_run;
-  return KG_OK;
+  if (bind(e) != KG_OK) return KG_ERR_HIP;
+  return ring_follow_config(e);
 }
 
 static int pick_delta_words(const kg_engine *e) {
@@ -470,7 +529,7 @@ extern "C" int kg_set_params(kg_engine *e, uint64_t dp_mask, const uint64_t *jd,
   HIPCHK(hipMemcpyAsync(e->jt, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->params_set = true;
-  return KG_OK;
+  return ring_follow_config(e);
 }
 
 // ---- herd upload / download --------------------------------------------------------------------------
@@ -660,17 +719,6 @@ extern "C" int kg_set_kangaroo(kg_engine *e, uint64_t k_idx, const uint64_t px[4
 }
 
 // ---- launch / collect ------------------------------------------------------------------------------------
-// bytes of the streaming kernel's launch-time workspace: slots, jump-index history, pacing table
-static size_t stream_ws_part(const kg_engine *e) {
-  return (size_t)WS_SLOT_WORDS * (size_t)e->K * (size_t)e->threads * sizeof(u32);
-}
-static size_t stream_hist_part(const kg_engine *e) {  // 16-byte aligned: the pacing table sits behind it
-  return ((size_t)e->nb_run * (size_t)e->K * (size_t)e->threads + 15) & ~(size_t)15;
-}
-static size_t stream_ws_need(const kg_engine *e) {
-  return stream_ws_part(e) + stream_hist_part(e) + (size_t)(PACE_KEYS * 4 + PACE_TAIL) * sizeof(u32);
-}
-
 static int kick_checks(kg_engine *e) {
   if (!e) return fail(KG_ERR_ARG, "kg_kick: null engine");
   if (!e->params_set || !e->herd_set) return fail(KG_ERR_STATE, "GPUEngine: Kernel: SetParams/SetKangaroos not called");
@@ -685,8 +733,7 @@ static int kick_checks(kg_engine *e) {
 // by the register-resident kernels.  Allocates nothing.
 static int launch_walk(kg_engine *e, void *ws) {
   const Variant *v = e->streaming ? nullptr : find_variant(e->K, e->DW);
-  const StreamVariant *sv = e->streaming ? find_stream_variant(e->DW) : nullptr;
-  if (!v && !sv) return fail(KG_ERR_STATE, "GPUEngine: Kernel: no kernel variant for this configuration");
+  if (!v && !e->streaming) return fail(KG_ERR_STATE, "GPUEngine: Kernel: no kernel variant for this configuration");
   const int b = e->next_buf;
   WalkArgs a;
   a.X = e->X;
@@ -701,41 +748,48 @@ static int launch_walk(kg_engine *e, void *ws) {
   a.jt = e->jt;
   a.out = e->out_dev[b];
   a.out_count = e->count_dev + b;
-  a.max_found = e->max_found;
-  const size_t lds = sv ? walk_stream_lds_bytes(e->DW) : walk_rot_lds_bytes(e->K, e->DW);
+  a.max_found = e->ring_cap[b];
+  const size_t lds = e->streaming ? walk_stream_lds_bytes() : walk_rot_lds_bytes(e->K, e->DW);
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit (gfx950 has 160 KiB per CU)
-    const void *fn = sv ? (const void *)sv->fn : (const void *)v->fn;
+    const void *fn = e->streaming ? (const void *)g_stream_fn : (const void *)v->fn;
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   HIPCHK(hipMemsetAsync(e->count_dev + b, 0, sizeof(u32), e->stream));
   HIPCHK(hipEventRecord(e->ev_start[b], e->stream));
-  if (sv) {
+  unsigned char *base = (unsigned char *)ws;
+  u32 *pace = nullptr;
+  if (e->streaming) {
     StreamArgs sa;
     sa.a = a;
     sa.ws = (u32 *)ws;
-    sa.hist = (unsigned char *)ws + stream_ws_part(e);
+    sa.hist = base + stream_ws_part(e);
     sa.K = (u32)e->K;
-    sa.pace = (u32 *)(sa.hist + stream_hist_part(e));
-    HIPCHK(hipMemsetAsync(sa.pace, 0, (size_t)(PACE_KEYS * 4 + PACE_TAIL) * sizeof(u32), e->stream));
-    hipLaunchKernelGGL(sv->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, sa);
+    pace = (u32 *)(sa.hist + stream_hist_part(e));
+    sa.pace = pace;
+    sa.dp_head = (u32 *)((unsigned char *)pace + stream_pace_part());
+    sa.dp_link = (DpLink *)((unsigned char *)sa.dp_head + stream_head_part(e));
+    HIPCHK(hipMemsetAsync(sa.pace, 0, stream_pace_part(), e->stream));
+    HIPCHK(hipMemsetAsync(sa.dp_head, 0xFF, stream_head_part(e), e->stream));  // DP_NONE
+    hipLaunchKernelGGL(g_stream_fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, sa);
     HIPCHK(hipGetLastError());
-    // distances: D += sum over the launch's jump-index history (inside the timed region)
+    // distances: D += sum over the launch's jump-index history, and the distances of the launch's DP items
+    // (inside the timed region)
     const u32 sum_grid = (u32)((e->cap / 2 + WALK_BLOCK - 1) / WALK_BLOCK);  // one thread per pair of slots and lane
     if (e->DW == 3)
       hipLaunchKernelGGL(kg_hist_sum_kernel<3>, dim3(sum_grid), dim3(WALK_BLOCK), 0, e->stream, sa.hist, e->jt, e->D,
-                         e->cap, e->n, e->threads, (u32)e->K, e->nb_run);
+                         e->cap, e->n, e->threads, (u32)e->K, e->nb_run, sa.dp_head, sa.dp_link, e->out_dev[b]);
     else
       hipLaunchKernelGGL(kg_hist_sum_kernel<8>, dim3(sum_grid), dim3(WALK_BLOCK), 0, e->stream, sa.hist, e->jt, e->D,
-                         e->cap, e->n, e->threads, (u32)e->K, e->nb_run);
+                         e->cap, e->n, e->threads, (u32)e->K, e->nb_run, sa.dp_head, sa.dp_link, e->out_dev[b]);
   } else {
     hipLaunchKernelGGL(v->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, a);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(e->ev_stop[b], e->stream));
   HIPCHK(hipMemcpyAsync(e->count_host + b, e->count_dev + b, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  if (sv)  // clock stamps written by workgroup 0 behind the pacing table
-    HIPCHK(hipMemcpyAsync(e->count_host + 2 + b * PACE_TAIL, (u32 *)((unsigned char *)ws + stream_ws_part(e) + stream_hist_part(e)) + PACE_KEYS * 4,
-                          PACE_TAIL * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+  if (pace)  // clock stamps written by workgroup 0 behind the pacing table
+    HIPCHK(hipMemcpyAsync(e->count_host + 2 + b * PACE_TAIL, pace + PACE_KEYS * 4, PACE_TAIL * sizeof(u32),
+                          hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipEventRecord(e->ev_done[b], e->stream));
   e->inflight = b;
   e->next_buf = b ^ 1;
@@ -745,8 +799,12 @@ static int launch_walk(kg_engine *e, void *ws) {
 extern "C" int kg_kick(kg_engine *e) {
   const int rc = kick_checks(e);
   if (rc != KG_OK) return rc;
+  // the DP buffer this launch appends to follows the configuration (the other one may still hold the previous
+  // launch's items, which kg_launch unpacks after this call)
+  const int rr = ring_ensure(e, e->next_buf);
+  if (rr != KG_OK) return rr;
   if (e->streaming) {
-    const size_t need = stream_ws_need(e);  // grows with nb_run (kg_set_nb_run); kept between launches
+    const size_t need = stream_ws_need(e);  // grows with nb_run (kg_set_nb_run) and the DP ring; kept between launches
     if (need > e->ws_bytes) {
       HIPCHK(hipStreamSynchronize(e->stream));
       if (e->ws) (void)hipFree(e->ws);
@@ -765,6 +823,9 @@ extern "C" int kg_kick_static(kg_engine *e) {
   const int rc = kick_checks(e);
   if (rc != KG_OK) return rc;
   if (!e->streaming) return fail(KG_ERR_ARG, "kg_kick_static: the engine does not run the streaming kernel");
+  if (e->ring_cap[e->next_buf] < ring_want(e))  // growing it would allocate: kg_set_params / kg_set_nb_run do that while idle
+    return fail(KG_ERR_STATE, "kg_kick_static: the DP ring is smaller than this configuration needs; call kg_set_params / "
+                              "kg_set_nb_run while no launch is in flight (they size it), or kg_kick once");
   const size_t need = stream_ws_need(e);
   if (need > (size_t)KG_STATIC_WORKSPACE_BYTES) {
     char msg[200];
@@ -789,7 +850,7 @@ static int wait_launch(kg_engine *e, int b) {
 
 static int unpack(kg_engine *e, int b, kg_item *items, uint32_t cap, uint32_t *n, uint32_t *lost) {
   const u32 found = e->count_host[b];
-  const u32 stored = std::min(found, e->max_found);
+  const u32 stored = std::min(found, e->ring_cap[b]);
   const u32 take = std::min(stored, cap);
   const DpItemDev *src = e->out_host[b];
   for (u32 i = 0; i < take; ++i) {
@@ -845,6 +906,12 @@ extern "C" int kg_launch(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *n
   return ru != KG_OK ? ru : rk;
 }
 
+extern "C" int kg_dp_capacity(const kg_engine *e, uint32_t *items) {
+  if (!e || !items) return fail(KG_ERR_ARG, "kg_dp_capacity: bad argument");
+  *items = std::max(std::max(e->ring_cap[0], e->ring_cap[1]), ring_want(e));
+  return KG_OK;
+}
+
 extern "C" int kg_kick_and_wait(kg_engine *e) {
   const int r = kg_kick(e);
   if (r != KG_OK) return r;
@@ -872,9 +939,7 @@ extern "C" int kg_kernel_name(const kg_engine *e, char *buf, size_t buflen) {
   if (!e || !buf || buflen == 0) return fail(KG_ERR_ARG, "kg_kernel_name: bad argument");
   const int dw = e->params_set ? pick_delta_words(e) : e->DW;
   if (e->streaming) {
-    const StreamVariant *sv = find_stream_variant(dw);
-    if (!sv) return fail(KG_ERR_STATE, "kg_kernel_name: no kernel variant for this configuration");
-    snprintf(buf, buflen, "kg_walk_kernel_stream<%d,%d>", sv->DW, sv->W);
+    snprintf(buf, buflen, "kg_walk_kernel_stream<%d>", KG_STREAM_W);
     return KG_OK;
   }
   const Variant *v = find_variant(e->K, dw);
@@ -889,7 +954,7 @@ extern "C" int kg_kernel_info(const kg_engine *e, int *k_per_lane, int *delta_wo
   const int dw = e->params_set ? pick_delta_words(e) : e->DW;
   if (k_per_lane) *k_per_lane = e->K;
   if (delta_words) *delta_words = dw;
-  if (lds_bytes) *lds_bytes = (int)(e->streaming ? walk_stream_lds_bytes(dw) : walk_rot_lds_bytes(e->K, dw));
+  if (lds_bytes) *lds_bytes = (int)(e->streaming ? walk_stream_lds_bytes() : walk_rot_lds_bytes(e->K, dw));
   if (grid) *grid = (int)e->grid;
   return KG_OK;
 }

@@ -13,6 +13,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <random>
@@ -603,7 +607,7 @@ struct Entry {
 constexpr int NSHARD = 256;
 constexpr u64 CELL_USED = 1ULL << 63;  // in Entry::d.v[3]: HashTable::Convert keeps only 62 bits of that limb
 struct Shard {
-  std::mutex mu;
+  mutable std::mutex mu;
   // One 64-byte cell per slot and nothing else (the reference's ENTRY is 64 bytes too, kangaroo.h:303-306): the key
   // is read back from the entry — x limbs 0 and 1 and the bucket number h = x.limb2 & 0x3FFFF — and bit 63 of
   // d.limb3 marks a used cell.
@@ -647,6 +651,84 @@ static inline U256 cell_d(const Entry &c) {
   return d;
 }
 
+// Worker pool owned by one solver.  Round 2 created up to 3 x nthreads std::threads per batch; with one GPU thread per
+// device feeding the table (core/kangaroo.cpp:780-786) that was eight producers each spawning 48 short-lived threads
+// per launch.  Here the threads exist once; a batch is a sequence of parallel-for jobs on a shared queue, the
+// submitting thread works on its own job as well (so eight concurrent producers are eight more workers, and a
+// producer never waits for a pool that is busy with another producer's batch), and jobs are served in arrival order.
+class WorkPool {
+ public:
+  ~WorkPool() { stop(); }
+  // at least `n` pool threads (beside the callers)
+  void ensure(int n) {
+    std::lock_guard<std::mutex> lock(mu_);
+    while ((int)th_.size() < n) th_.emplace_back([this] { loop(); });
+  }
+  // fn(i) for every i in [0, total); returns when all are done.  Callable from several threads at once.
+  void parallel_for(int total, const std::function<void(int)> &fn) {
+    if (total <= 0) return;
+    auto job = std::make_shared<Job>();
+    job->fn = &fn;
+    job->total = total;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      jobs_.push_back(job);
+    }
+    cv_work_.notify_all();
+    work(*job);
+    std::unique_lock<std::mutex> lock(mu_);
+    cv_done_.wait(lock, [&] { return job->done.load() == job->total; });
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      stop_ = true;
+    }
+    cv_work_.notify_all();
+    for (auto &t : th_) t.join();
+    th_.clear();
+  }
+
+ private:
+  struct Job {
+    const std::function<void(int)> *fn = nullptr;
+    int total = 0;
+    std::atomic<int> next{0}, done{0};
+  };
+  void work(Job &j) {
+    for (;;) {
+      const int i = j.next.fetch_add(1);
+      if (i >= j.total) return;
+      (*j.fn)(i);
+      if (j.done.fetch_add(1) + 1 == j.total) {
+        std::lock_guard<std::mutex> lock(mu_);  // pairs with the wait in parallel_for
+        cv_done_.notify_all();
+      }
+    }
+  }
+  void loop() {
+    for (;;) {
+      std::shared_ptr<Job> job;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        for (;;) {
+          while (!jobs_.empty() && jobs_.front()->next.load() >= jobs_.front()->total) jobs_.pop_front();  // fully claimed
+          if (stop_ || !jobs_.empty()) break;
+          cv_work_.wait(lock);
+        }
+        if (stop_) return;
+        job = jobs_.front();
+      }
+      work(*job);
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_done_;
+  std::deque<std::shared_ptr<Job>> jobs_;
+  std::vector<std::thread> th_;
+  bool stop_ = false;
+};
+
 struct kgh_solver {
   U256 range_start, range_end, width, width2;
   int range_power;
@@ -656,7 +738,12 @@ struct kgh_solver {
   std::atomic<bool> found{false};
   U256 priv;
   std::atomic<u64> dead{0};
-  int threads = 0;  // worker threads for large batches (0: hardware concurrency, capped at 16)
+  // items handed in that ended up neither in the table nor dead: the DP that solved the key, tame/wild collisions
+  // that arrived after it, and whatever a batch still held when the key was found.  table + dead + unstored ==
+  // items handed in, always.
+  std::atomic<u64> unstored{0};
+  int threads = 0;  // threads working on a large batch, the caller included (0: hardware concurrency, capped at 16)
+  WorkPool pool;
 };
 static inline int shard_of(const Key128 &k) { return (int)((k.lo * 0x9E3779B97F4A7C15ULL) >> 56); }
 
@@ -754,8 +841,12 @@ static int resolve_collision(kgh_solver *s, const U256 &d, const U256 &d0, uint3
 static int add_one(kgh_solver *s, const U256 &x, const U256 &d, u64 k_idx) {
   U256 d0;
   uint32_t t0;
-  const int r = shard_add(s, x, d, k_idx, &d0, &t0);
-  return r == 3 ? resolve_collision(s, d, d0, t0) : r;
+  int r = shard_add(s, x, d, k_idx, &d0, &t0);
+  if (r == 3) {
+    r = resolve_collision(s, d, d0, t0);
+    if (r == 2) s->unstored++;
+  }
+  return r;
 }
 
 kgh_solver *kgh_solver_new(const uint64_t range_start[4], const uint64_t range_end[4], const uint64_t pub_x[4],
@@ -787,7 +878,10 @@ void kgh_solver_search_key(const kgh_solver *s, uint64_t x[4], uint64_t y[4]) {
   store(y, s->key.y);
 }
 int kgh_solver_add(kgh_solver *s, const uint64_t x[4], const uint64_t d[4], uint64_t k_idx) {
-  if (s->found) return 2;
+  if (s->found) {
+    s->unstored++;
+    return 2;
+  }
   return add_one(s, load(x), load(d), k_idx);
 }
 void kgh_solver_set_threads(kgh_solver *s, int threads) { s->threads = threads < 0 ? 0 : threads; }
@@ -803,88 +897,76 @@ int kgh_solver_add_items(kgh_solver *s, const void *items, uint32_t n, uint32_t 
   int nthreads = s->threads > 0 ? s->threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 16u);
   if (nthreads < 1) nthreads = 1;
   if (n < PAR_BATCH || nthreads == 1) {
-    for (uint32_t i = 0; i < n && !s->found; ++i) {
+    uint32_t i = 0;
+    for (; i < n && !s->found; ++i) {
       const int r = add_one(s, load(it[i].x), load(it[i].d), it[i].kIdx);
       if (r == 0 && dead) dead[nd++] = i;
     }
+    s->unstored += n - i;  // what the batch still held when the key was found
     if (n_dead) *n_dead = nd;
     return s->found ? 2 : 0;
   }
-  // 1. bucket the item indices by shard, keeping arrival order inside each shard
+  s->pool.ensure(nthreads - 1);  // the calling thread is the nthreads-th worker
+  // 1. bucket the item indices by shard, keeping arrival order inside each shard: the batch is cut into nslice
+  //    consecutive slices, counted and scattered slice by slice
+  const int nslice = nthreads;
+  const uint32_t per = (n + nslice - 1) / nslice;
   std::vector<uint32_t> start(NSHARD + 1, 0), order(n);
   std::vector<uint8_t> sid(n);
+  std::vector<std::vector<uint32_t>> cnt(nslice, std::vector<uint32_t>(NSHARD, 0)), off(nslice, std::vector<uint32_t>(NSHARD, 0));
+  s->pool.parallel_for(nslice, [&](int t) {
+    const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
+    for (uint32_t i = lo; i < hi; ++i) {
+      Key128 k;
+      k.lo = it[i].x[0];
+      const int sh = shard_of(k);
+      sid[i] = (uint8_t)sh;
+      cnt[t][sh]++;
+    }
+  });
   {
-    std::vector<std::thread> th;
-    const uint32_t per = (n + nthreads - 1) / nthreads;
-    std::vector<std::vector<uint32_t>> cnt(nthreads, std::vector<uint32_t>(NSHARD, 0));
-    for (int t = 0; t < nthreads; ++t)
-      th.emplace_back([&, t] {
-        const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
-        for (uint32_t i = lo; i < hi; ++i) {
-          Key128 k;
-          k.lo = it[i].x[0];
-          const int sh = shard_of(k);
-          sid[i] = (uint8_t)sh;
-          cnt[t][sh]++;
-        }
-      });
-    for (auto &x : th) x.join();
-    th.clear();
-    // offsets: shard-major, thread-minor (threads hold consecutive slices, so this is arrival order)
-    std::vector<std::vector<uint32_t>> off(nthreads, std::vector<uint32_t>(NSHARD, 0));
+    // offsets: shard-major, slice-minor (slices are consecutive, so this is arrival order)
     uint32_t run = 0;
     for (int sh = 0; sh < NSHARD; ++sh) {
       start[sh] = run;
-      for (int t = 0; t < nthreads; ++t) {
+      for (int t = 0; t < nslice; ++t) {
         off[t][sh] = run;
         run += cnt[t][sh];
       }
     }
     start[NSHARD] = run;
-    for (int t = 0; t < nthreads; ++t)
-      th.emplace_back([&, t] {
-        const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
-        for (uint32_t i = lo; i < hi; ++i) order[off[t][sid[i]]++] = i;
-      });
-    for (auto &x : th) x.join();
   }
-  // 2. shards in parallel; dead kangaroos and tame/wild collisions are recorded per worker
+  s->pool.parallel_for(nslice, [&](int t) {
+    const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
+    for (uint32_t i = lo; i < hi; ++i) order[off[t][sid[i]]++] = i;
+  });
+  // 2. shards in parallel; dead kangaroos and tame/wild collisions are recorded per shard
   struct Coll {
     uint32_t idx;
     U256 d0;
     uint32_t t0;
   };
-  std::vector<std::vector<uint32_t>> wdead(nthreads);
-  std::vector<std::vector<Coll>> wcoll(nthreads);
-  std::atomic<int> next{0};
-  {
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; ++t)
-      th.emplace_back([&, t] {
-        for (;;) {
-          const int sh = next.fetch_add(1);
-          if (sh >= NSHARD) break;
-          for (uint32_t q = start[sh]; q < start[sh + 1]; ++q) {
-            const uint32_t i = order[q];
-            U256 d0;
-            uint32_t t0;
-            const int r = shard_add(s, load(it[i].x), load(it[i].d), it[i].kIdx, &d0, &t0);
-            if (r == 0) wdead[t].push_back(i);
-            else if (r == 3) wcoll[t].push_back(Coll{i, d0, t0});
-          }
-        }
-      });
-    for (auto &x : th) x.join();
-  }
+  std::vector<std::vector<uint32_t>> sdead(NSHARD);
+  std::vector<std::vector<Coll>> scoll(NSHARD);
+  s->pool.parallel_for(NSHARD, [&](int sh) {
+    for (uint32_t q = start[sh]; q < start[sh + 1]; ++q) {
+      const uint32_t i = order[q];
+      U256 d0;
+      uint32_t t0;
+      const int r = shard_add(s, load(it[i].x), load(it[i].d), it[i].kIdx, &d0, &t0);
+      if (r == 0) sdead[sh].push_back(i);
+      else if (r == 3) scoll[sh].push_back(Coll{i, d0, t0});
+    }
+  });
   // 3. collisions between herds, in arrival order (EC arithmetic, rare)
   std::vector<Coll> coll;
-  for (auto &v : wcoll) coll.insert(coll.end(), v.begin(), v.end());
+  for (auto &v : scoll) coll.insert(coll.end(), v.begin(), v.end());
   std::sort(coll.begin(), coll.end(), [](const Coll &a, const Coll &b) { return a.idx < b.idx; });
   std::vector<uint32_t> all_dead;
-  for (auto &v : wdead) all_dead.insert(all_dead.end(), v.begin(), v.end());
+  for (auto &v : sdead) all_dead.insert(all_dead.end(), v.begin(), v.end());
   for (const Coll &c : coll) {
-    if (s->found) break;
     if (resolve_collision(s, load(it[c.idx].d), c.d0, c.t0) == 0) all_dead.push_back(c.idx);
+    else s->unstored++;  // the DP that solves the key, or a collision that arrived after it
   }
   std::sort(all_dead.begin(), all_dead.end());
   if (dead)
@@ -899,13 +981,18 @@ int kgh_solver_found(const kgh_solver *s, uint64_t priv[4]) {
 }
 uint64_t kgh_solver_table_size(const kgh_solver *s) {
   uint64_t n = 0;
-  for (const Shard &sh : s->shard) n += sh.used;
+  for (const Shard &sh : s->shard) {
+    std::lock_guard<std::mutex> lock(sh.mu);
+    n += sh.used;
+  }
   return n;
 }
 uint64_t kgh_solver_dead_count(const kgh_solver *s) { return s->dead; }
+uint64_t kgh_solver_unstored_count(const kgh_solver *s) { return s->unstored; }
 uint64_t kgh_solver_dump(const kgh_solver *s, uint64_t *out, uint64_t cap) {
   uint64_t n = 0;
-  for (const Shard &sh : s->shard)
+  for (const Shard &sh : s->shard) {
+    std::lock_guard<std::mutex> lock(sh.mu);  // a concurrent insert may grow (reallocate) the shard
     for (const Entry &c : sh.cells) {
       if (!Shard::occupied(c)) continue;
       if (n >= cap) return n;
@@ -915,6 +1002,7 @@ uint64_t kgh_solver_dump(const kgh_solver *s, uint64_t *out, uint64_t cap) {
       memcpy(out + 9 * n + 5, d.v, 32);
       ++n;
     }
+  }
   return n;
 }
 
@@ -951,25 +1039,29 @@ int kgh_work_save(const kgh_solver *s, const char *path, uint32_t dp_size, uint6
   bool ok = wr(f, &HEADW_MAGIC, 4) && wr(f, &version, 4) && wr(f, &dp_size, 4) && wr(f, s->range_start.v, 32) &&
             wr(f, s->range_end.v, 32) && wr(f, s->pub.x.v, 32) && wr(f, s->pub.y.v, 32) && wr(f, &total_count, 8) &&
             wr(f, &total_time, 8);
-  // gather the shards into the reference's 2^18 buckets
-  std::vector<uint32_t> cnt(HASH_BUCKETS + 1, 0);
-  for (const Shard &sh : s->shard)
+  // gather the shards into the reference's 2^18 buckets.  Each shard is copied out under its mutex in ONE scan (the
+  // reference saves with every worker parked, storage/backup.cpp:327-345; this must also be safe if a producer is
+  // still inserting: a concurrent grow() reallocates the cells), the counting sort runs on the copy.
+  struct Snap {
+    uint32_t h;
+    FileEntry e;
+  };
+  std::vector<Snap> snap;
+  for (const Shard &sh : s->shard) {
+    std::lock_guard<std::mutex> lock(sh.mu);
+    snap.reserve(snap.size() + sh.used);
     for (const Entry &c : sh.cells)
-      if (Shard::occupied(c)) cnt[Shard::key_of(c).h + 1]++;
+      if (Shard::occupied(c)) snap.push_back(Snap{(uint32_t)Shard::key_of(c).h, FileEntry{{c.x.v[0], c.x.v[1]}, {c.d.v[0], c.d.v[1]}}});
+  }
+  std::vector<uint32_t> cnt(HASH_BUCKETS + 1, 0);
+  for (const Snap &q : snap) cnt[q.h + 1]++;
   for (uint32_t h = 0; h < HASH_BUCKETS; ++h) cnt[h + 1] += cnt[h];
   std::vector<FileEntry> all(cnt[HASH_BUCKETS]);
   {
     std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
-    for (const Shard &sh : s->shard)
-      for (const Entry &c : sh.cells)
-        if (Shard::occupied(c)) {
-          FileEntry &e = all[pos[Shard::key_of(c).h]++];
-          e.x[0] = c.x.v[0];
-          e.x[1] = c.x.v[1];
-          e.d[0] = c.d.v[0];
-          e.d[1] = c.d.v[1];
-        }
+    for (const Snap &q : snap) all[pos[q.h]++] = q.e;
   }
+  std::vector<Snap>().swap(snap);
   for (uint32_t h = 0; h < HASH_BUCKETS && ok; ++h) {
     FileEntry *b = all.data() + cnt[h];
     const uint32_t nb = cnt[h + 1] - cnt[h];

@@ -30,6 +30,16 @@
 
 namespace kg {
 
+// Distinguished points of the streaming kernel.  The walk does not carry distances (see below), so a reporting lane
+// writes x and kIdx only and chains the item to its kangaroo (dp_head / dp_link, device memory); kg_hist_sum_kernel, which
+// reads every kangaroo's jump history anyway, fills in the distances of the chained items afterwards.  Round 2 had the
+// reporting lane re-sum its own history from HBM inside the walk kernel: a divergent loop of up to nb_run iterations
+// that cost 27 % of the throughput at DP = 8 (one DP per kangaroo and launch).
+struct DpLink {
+  u32 prev;  // ring position of the same kangaroo's previous item of this launch, DP_NONE if this was its first
+  u32 step;  // jump of the launch (0-based) that produced the distinguished point
+};
+constexpr u32 DP_NONE = 0xFFFFFFFFu;
 struct StreamArgs {
   WalkArgs a;
   u32 *ws;            // workspace, WS_ROWS * K rows of a.threads 16-byte entries
@@ -37,6 +47,8 @@ struct StreamArgs {
   u32 K;              // kangaroos per lane
   u32 *pace;          // [PACE_KEYS][4]: per physical CU {claim counter, pass of workgroup 0, pass of workgroup 1, -}, zeroed per launch;
                       // behind it PACE_TAIL words: the clock stamps of workgroup 0 (shader cycles, 100 MHz reference ticks)
+  u32 *dp_head;       // [cap]: ring position of the kangaroo's most recent distinguished point of this launch, DP_NONE if none
+  DpLink *dp_link;    // [max_found]: per reported item, the kangaroo's previous item and the step it was found at
 };
 constexpr u32 PACE_KEYS = 4096;
 constexpr u32 PACE_TAIL = 4;
@@ -129,13 +141,12 @@ struct StreamRec {  // one kangaroo as it travels through the registers between 
   pk256 x, y;
 };
 
-template <int DW, int W>
+template <int W>
 __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArgs sa) {
   const WalkArgs &a = sa.a;
   extern __shared__ u32 lds[];
   u32 *jt = lds;                           // [64][JT_STRIDE]
-  u32 *jdist = lds + NB_JUMP * JT_STRIDE;  // [64][DW]
-  u32 *inv_ex = jdist + NB_JUMP * DW;      // [8][9][64]: products in, inverses out (shared inversion)
+  u32 *inv_ex = lds + NB_JUMP * JT_STRIDE;  // [8][9][64]: products in, inverses out (shared inversion)
 
   const u32 tid = threadIdx.x;
   // clock stamps (workgroup 0 reports them at the end): the shader clock counter against the constant 100 MHz
@@ -145,7 +156,6 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     u32 row = i / 18, col = i % 18;
     jt[row * JT_STRIDE + col] = a.jt->pxy[row][col];
   }
-  for (u32 i = tid; i < NB_JUMP * DW; i += WALK_BLOCK) jdist[i] = a.jt->dist[i / DW][i % DW];
   // physical CU of this workgroup: HW_ID (cu_id 11:8, sh_id 12, se_id 15:13) and XCC_ID; first come, first slot
   const u32 pace_key = ((__builtin_amdgcn_s_getreg(0xF804) >> 8) & 0xFFu) | ((__builtin_amdgcn_s_getreg(0x1814) & 0xFu) << 8);
   if (tid == 0) inv_ex[8 * 9 * 64] = atomicAdd(sa.pace + pace_key * 4, 1u) & 1u;
@@ -164,27 +174,6 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   // jump-index history: one 16-bit entry per step, PAIR of slots (2j, 2j+1) and lane; low byte = the even slot's jump
   unsigned short *hist16 = (unsigned short *)sa.hist;
   const u32 half_k = K >> 1;
-  // distance travelled by slot id in steps [0, steps): sum of the jump distances in its history (used by the
-  // lanes that report a distinguished point; the end-of-launch sums are kg_hist_sum_kernel's job)
-  auto travelled = [&](dlt<DW> &sum, u32 steps, u32 id) {
-#pragma unroll
-    for (int i = 0; i < DW; ++i) sum.w[i] = 0u;
-    const unsigned char *col = sa.hist + ((u64)(id >> 1) * threads + Tl) * 2u + (id & 1u);  // + step * K * threads
-    constexpr u32 CH = 4;  // history bytes requested together (rare path: kept small, it costs SGPRs)
-#pragma unroll 1
-    for (u32 r0 = 0; r0 < steps; r0 += CH) {
-      u32 j[CH];
-#pragma unroll
-      for (u32 i = 0; i < CH; ++i) {
-        const u32 r = r0 + i < steps ? r0 + i : r0;  // clamped: a valid row, masked out below
-        j[i] = col[(u64)r * K * threads];
-      }
-#pragma unroll
-      for (u32 i = 0; i < CH; ++i)
-        if (r0 + i < steps) delta_add<DW>(sum.w, jdist + j[i] * DW);
-    }
-  };
-
   // ---- prologue: X/Y planes -> workspace (the planes hold canonical values: eight words as they are), prefix
   // products of the first step's dx (ascending) ----
   fe acc;
@@ -217,8 +206,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
 
   // one jump of the kangaroo (x, y) in slot id given dx^-1; multiplies its next dx into acc, stores the new
   // point (and, for the second kangaroo of a pair, the running product), reports a distinguished point
-  auto jump = [&](const fe &x, const fe &y, const fe &dxi, const fe &jx, const u32 *row, u32 jmp, u32 id, u32 run,
-                  bool with_p) {
+  auto jump = [&](const fe &x, const fe &y, const fe &dxi, const fe &jx, const u32 *row, u32 id, u32 run, bool with_p) {
     fe jy;
 #pragma unroll
     for (int i = 0; i < 9; ++i) jy.l[i] = row[9 + i];
@@ -275,14 +263,12 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
             it->x[i] = xw.lo[i];
             it->x[4 + i] = xw.hi[i];
           }
-          u32 w[8];
-          dlt<DW> dl;
-          travelled(dl, run, id);  // steps before this one, from the history (this branch is rare)
-          delta_add<DW>(dl.w, jdist + jmp * DW);
-          add_dist_256<DW>(w, a.D, a.cap, p, dl);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) it->d[i] = w[i];
           it->kidx = p;
+          // the distance is filled in by kg_hist_sum_kernel: chain the item to its kangaroo.  Only this lane ever
+          // touches the head of kangaroo p; the exchange is an atomic so that it is served by the L2 and never by
+          // a stale line of this CU's vector cache
+          const u32 prev = atomicExch(sa.dp_head + p, pos);
+          sa.dp_link[pos] = DpLink{prev, run};
         }
       }
     }
@@ -438,7 +424,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
         __builtin_amdgcn_sched_barrier(0);
         ws_load<2>(A.y, wr, id_at(s2));
         __builtin_amdgcn_sched_barrier(0);
-        jump(xA, yA, dxiA, jxA, rowA, jmpA, idA, run, !KG_WS_PAIRS);
+        jump(xA, yA, dxiA, jxA, rowA, idA, run, !KG_WS_PAIRS);
       }
       {
         fe yB;
@@ -446,7 +432,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
         __builtin_amdgcn_sched_barrier(0);
         ws_load<2>(B.y, wr, id_at(s2 + 1));
         __builtin_amdgcn_sched_barrier(0);
-        jump(xB, yB, dxiB, jxB, rowB, jmpB, idB, run, true);
+        jump(xB, yB, dxiB, jxB, rowB, idB, run, true);
       }
     }
   } while (++run < a.nb_run);
@@ -475,12 +461,28 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   }
 }
 
-// End of launch: D[p] += sum of the jump distances in kangaroo p's history.  One thread per PAIR of slots and lane
-// (the history holds the two jump indices of a pair in one 16-bit entry), full occupancy, lane-contiguous reads
-// (1 B per jump read once).
+// 256-bit value minus a DW-word one (the distance at the end of the launch minus what was travelled after a step)
+template <int DW>
+__device__ __forceinline__ void sub_dist_256(u32 (&out)[8], const u32 (&end)[8], const dlt<DW> &sfx) {
+  u32 br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u64 t = (u64)end[i] - (i < DW ? sfx.w[i < DW ? i : 0] : 0u) - br;
+    out[i] = (u32)t;
+    br = (u32)(t >> 63);
+  }
+}
+
+// End of launch: D[p] += sum of the jump distances in kangaroo p's history, and the distances of the launch's
+// distinguished points.  One thread per PAIR of slots and lane (the history holds the two jump indices of a pair in
+// one 16-bit entry), full occupancy, lane-contiguous reads (1 B per jump read once).  A kangaroo that reported
+// distinguished points has them chained from dp_head[p], most recent first: its thread walks the history a second
+// time, downwards from the last step, and writes  d(item) = D_end - (distance travelled after the item's step)
+// into the pinned ring (math/gpu/compute.h:48,57: the reference adds the jump distance before it reports).
 template <int DW>
 __global__ void __launch_bounds__(WALK_BLOCK) kg_hist_sum_kernel(const unsigned char *hist, const JumpTableDev *jtab, u64 *D,
-                                                                 u64 cap, u64 n, u32 threads, u32 K, u32 nb_run) {
+                                                                 u64 cap, u64 n, u32 threads, u32 K, u32 nb_run,
+                                                                 const u32 *dp_head, const DpLink *dp_link, DpItemDev *out) {
   __shared__ u32 jdist[NB_JUMP * DW];
   for (u32 i = threadIdx.x; i < NB_JUMP * DW; i += WALK_BLOCK) jdist[i] = jtab->dist[i / DW][i % DW];
   __syncthreads();
@@ -508,18 +510,53 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_hist_sum_kernel(const unsigned 
     delta_add<DW>(s0.w, jdist + (j & 0xFFu) * DW);
     delta_add<DW>(s1.w, jdist + (j >> 8) * DW);
   }
-  u32 w[8];
+  u32 e0[8], e1[8];
   const u64 p0 = (u64)(2 * pair) * threads + lane, p1 = p0 + threads;
-  add_dist_256<DW>(w, D, cap, p0, s0);
+  add_dist_256<DW>(e0, D, cap, p0, s0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) D[(u64)i * cap + p0] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
-  add_dist_256<DW>(w, D, cap, p1, s1);
+  for (int i = 0; i < 4; ++i) D[(u64)i * cap + p0] = (u64)e0[2 * i] | ((u64)e0[2 * i + 1] << 32);
+  add_dist_256<DW>(e1, D, cap, p1, s1);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) D[(u64)i * cap + p1] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
+  for (int i = 0; i < 4; ++i) D[(u64)i * cap + p1] = (u64)e1[2 * i] | ((u64)e1[2 * i + 1] << 32);
+
+  // distinguished points of this launch (rare unless the DP size is very low)
+  u32 h0 = dp_head[p0], h1 = dp_head[p1];
+  if (h0 == DP_NONE && h1 == DP_NONE) return;
+#pragma unroll
+  for (int i = 0; i < DW; ++i) s0.w[i] = s1.w[i] = 0u;  // now: distance travelled in the steps (r, nb_run)
+  DpLink l0 = h0 != DP_NONE ? dp_link[h0] : DpLink{DP_NONE, 0u}, l1 = h1 != DP_NONE ? dp_link[h1] : DpLink{DP_NONE, 0u};
+  r = nb_run;  // steps [r, nb_run) are in the suffix sums
+  while (h0 != DP_NONE || h1 != DP_NONE) {
+    // the later of the two chains' next steps (a chain's steps strictly decrease along prev)
+    const u32 t0 = h0 != DP_NONE ? l0.step : 0u, t1 = h1 != DP_NONE ? l1.step : 0u;
+    const u32 t = h0 == DP_NONE ? t1 : h1 == DP_NONE ? t0 : (t0 > t1 ? t0 : t1);
+    while (r > t + 1) {
+      --r;
+      const u32 j = col[(u64)r * step_stride];
+      delta_add<DW>(s0.w, jdist + (j & 0xFFu) * DW);
+      delta_add<DW>(s1.w, jdist + (j >> 8) * DW);
+    }
+    if (h0 != DP_NONE && l0.step == t) {
+      u32 w[8];
+      sub_dist_256<DW>(w, e0, s0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[h0].d[i] = w[i];
+      h0 = l0.prev;
+      if (h0 != DP_NONE) l0 = dp_link[h0];
+    }
+    if (h1 != DP_NONE && l1.step == t) {
+      u32 w[8];
+      sub_dist_256<DW>(w, e1, s1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[h1].d[i] = w[i];
+      h1 = l1.prev;
+      if (h1 != DP_NONE) l1 = dp_link[h1];
+    }
+  }
 }
 
-constexpr size_t walk_stream_lds_bytes(int DW) {
-  return (size_t)(NB_JUMP * JT_STRIDE + NB_JUMP * DW + 8 * 9 * 64 + 4) * sizeof(u32);  // + the pacing slot
+constexpr size_t walk_stream_lds_bytes() {
+  return (size_t)(NB_JUMP * JT_STRIDE + 8 * 9 * 64 + 4) * sizeof(u32);  // + the pacing slot
 }
 
 }  // namespace kg

@@ -16,8 +16,10 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world)."""
+def init(backend=None, timeout_s=600.0):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world).
+    timeout_s bounds the rendezvous and every collective: a rank that died must not leave the others waiting for
+    the default half hour (the only collectives here are barriers and reductions of a few bytes)."""
     rank, local_rank, world = env_world()
     if world > 1:
         import torch
@@ -29,7 +31,10 @@ def init(backend=None):
             if backend == "nccl":
                 torch.cuda.set_device(local_rank)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            import datetime
+
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=timeout_s))
     return rank, local_rank, world
 
 

@@ -138,13 +138,17 @@ bool GPUEngine::callKernelAndWait() {
 }
 
 bool GPUEngine::Launch(std::vector<ITEM> &hashFound, bool spinWait) {
-  (void)spinWait;  // the engine always blocks on its stream's event; there is no spin variant
+  // spinWait (engine.cu:486-500: poll the event in a loop instead of blocking on it) is accepted and has no effect:
+  // the engine always blocks on its stream's event, which costs no CPU while the GPU walks
+  (void)spinWait;
   hashFound.clear();
   if (!resultReady) return false;
+  // staging for one launch's items, per host thread (one engine per thread, core/kangaroo.cpp:397-408); sized from
+  // the engine's DP ring, which follows the DP mask (kg_dp_capacity), never below the caller's maxFound
   static thread_local std::vector<kg_item> items;
-  const uint64_t herd = kg_nb_kangaroo(handle_of(resultReady));
-  const uint32_t ring = (uint32_t)(2 * herd < (1u << 22) ? 2 * herd : (1u << 22));  // the engine's own ring depth
-  const uint32_t cap = maxFound > ring ? maxFound : ring;
+  uint32_t cap = maxFound;
+  if (!report(kg_dp_capacity(handle_of(resultReady), &cap), "Launch")) return false;
+  if (cap < maxFound) cap = maxFound;
   if (items.size() < cap) items.resize(cap);
   uint32_t n = 0, lost = 0;
   const int rc = kg_launch(handle_of(resultReady), items.data(), cap, &n, &lost);

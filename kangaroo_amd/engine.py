@@ -29,7 +29,7 @@ class _CItem(C.Structure):
 
 
 class _CTuning(C.Structure):
-    _fields_ = [("mode", C.c_int), ("k_per_lane", C.c_int)]
+    _fields_ = [("mode", C.c_int), ("k_per_lane", C.c_int), ("ring_max_items", C.c_uint32)]
 
 
 MODE_AUTO, MODE_STREAM, MODE_REG = 0, 1, 2
@@ -80,6 +80,7 @@ def load_library():
         "kg_collect": ([H, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)], C.c_int),
         "kg_launch": ([H, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)], C.c_int),
         "kg_kick_and_wait": ([H], C.c_int),
+        "kg_dp_capacity": ([H, C.POINTER(C.c_uint32)], C.c_int),
         "kg_last_kernel_ms": ([H, C.POINTER(C.c_float)], C.c_int),
         "kg_last_kernel_clock": ([H, _u64p, _u64p], C.c_int),
         "kg_kernel_info": ([H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
@@ -103,7 +104,7 @@ ABI_SYMBOLS = [
     "kg_device_count", "kg_default_grid", "kg_create", "kg_create_tuned", "kg_destroy", "kg_device_name", "kg_memory_bytes",
     "kg_nb_thread", "kg_group_size", "kg_nb_kangaroo", "kg_set_wild_offset", "kg_set_params", "kg_set_kangaroos",
     "kg_get_kangaroos", "kg_herd_from_distances", "kg_set_kangaroo", "kg_set_nb_run", "kg_kick", "kg_kick_static", "kg_collect", "kg_launch",
-    "kg_kick_and_wait", "kg_last_kernel_ms", "kg_last_kernel_clock", "kg_kernel_info", "kg_kernel_name", "kg_field_kat", "kg_alloc_pinned", "kg_free_pinned",
+    "kg_kick_and_wait", "kg_dp_capacity", "kg_last_kernel_ms", "kg_last_kernel_clock", "kg_kernel_info", "kg_kernel_name", "kg_field_kat", "kg_alloc_pinned", "kg_free_pinned",
     "kg_print_device_info", "kg_last_error", "kg_version",
 ]
 
@@ -133,21 +134,22 @@ def _limbs(v):
 class GPUEngine:
     """GPUEngine(nbThreadGroup, nbThreadPerGroup, gpuId, maxFound) — math/gpu/engine.cu:67-170."""
 
-    def __init__(self, nbThreadGroup, nbThreadPerGroup, gpuId, maxFound, mode=None, k_per_lane=0):
-        """mode / k_per_lane: kg_tuning (kg_create_tuned); mode is None, "stream" or "reg"."""
+    def __init__(self, nbThreadGroup, nbThreadPerGroup, gpuId, maxFound, mode=None, k_per_lane=0, ring_max=0):
+        """mode / k_per_lane / ring_max: kg_tuning (kg_create_tuned); mode is None, "stream" or "reg"; ring_max caps
+        the DP ring (items per launch), 0 = the engine's default."""
         self._L = load_library()
         self._h = C.c_void_p()
-        if mode is None and not k_per_lane:
+        if mode is None and not k_per_lane and not ring_max:
             _chk(self._L.kg_create(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, C.byref(self._h)))
         else:
-            t = _CTuning({None: MODE_AUTO, "stream": MODE_STREAM, "reg": MODE_REG}[mode], int(k_per_lane or 0))
+            t = _CTuning({None: MODE_AUTO, "stream": MODE_STREAM, "reg": MODE_REG}[mode], int(k_per_lane or 0), int(ring_max or 0))
             _chk(self._L.kg_create_tuned(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, C.byref(t), C.byref(self._h)))
         buf = C.create_string_buffer(256)
         _chk(self._L.kg_device_name(self._h, buf, 256))
         self.deviceName = buf.value.decode()
         self.nbKangaroo = int(self._L.kg_nb_kangaroo(self._h))
-        self._cap = max(int(maxFound), min(2 * self.nbKangaroo, 1 << 22))
-        self._items = np.zeros(self._cap, dtype=ITEM_DTYPE)
+        self._cap = 0
+        self._items = None  # staging array for kg_collect / kg_launch, sized from kg_dp_capacity when first needed
         self.lost = 0
         self.nb_run = 256  # NB_RUN, constants.h:21
 
@@ -261,7 +263,17 @@ class GPUEngine:
         _chk(self._L.kg_kick_and_wait(self._h))
         return True
 
-    def _finish(self, fn):
+    def DpCapacity(self):
+        """Items one launch can return under the current configuration (kg_dp_capacity)."""
+        c = C.c_uint32(0)
+        _chk(self._L.kg_dp_capacity(self._h, C.byref(c)))
+        return c.value
+
+    def _finish(self, fn, copy):
+        cap = self.DpCapacity()  # follows SetParams / SetNbRun
+        if self._items is None or cap > self._cap:
+            self._cap = cap
+            self._items = np.empty(cap, dtype=ITEM_DTYPE)
         n, lost = C.c_uint32(0), C.c_uint32(0)
         rc = fn(self._h, self._items.ctypes.data, self._cap, C.byref(n), C.byref(lost))
         self.lost = lost.value
@@ -270,15 +282,20 @@ class GPUEngine:
         if rc == KG_ERR_LOST:
             # the reference prints this and exits (engine.cu:506-510)
             raise KgError(rc, self._L.kg_last_error().decode())
-        return self._items[: n.value].copy()  # the staging array is reused by the next call
+        out = self._items[: n.value]
+        return out.copy() if copy else out  # the staging array is reused by the next call
 
-    def Launch(self, spinWait=False):
-        """Wait for the launch in flight, return its DPs (structured array x,d,kIdx), start the next."""
-        return self._finish(self._L.kg_launch)
+    def Launch(self, spinWait=False, copy=True):
+        """Wait for the launch in flight, return its DPs (structured array x,d,kIdx), start the next.
+        copy=False returns a view of the engine's staging array, valid until the next Launch / Collect: for callers
+        that consume the items at once (at DP = 8 a launch of the default herd returns 600 MB of them).
+        spinWait: the reference polls the event in a loop instead of blocking on it (engine.cu:486-500); this engine
+        always blocks on its stream's event, the flag is accepted and has no effect."""
+        return self._finish(self._L.kg_launch, copy)
 
-    def Collect(self):
+    def Collect(self, copy=True):
         """Wait for the launch in flight and return its DPs without starting another."""
-        return self._finish(self._L.kg_collect)
+        return self._finish(self._L.kg_collect, copy)
 
 
 def items_to_tuples(items):

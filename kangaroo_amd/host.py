@@ -13,7 +13,7 @@ HOST_SYMBOLS = [
     "kgh_ec_mul_g", "kgh_ec_mul_g_batch", "kgh_ec_add", "kgh_parse_pubkey", "kgh_create_jump_table", "kgh_rng_new",
     "kgh_rng_free", "kgh_rng_next", "kgh_create_herd", "kgh_herd_distances", "kgh_comb_table", "kgh_synthetic_herd", "kgh_solver_new", "kgh_solver_free", "kgh_solver_set_threads", "kgh_work_save", "kgh_work_info", "kgh_work_load",
     "kgh_solver_range_power", "kgh_solver_wild_offset", "kgh_solver_range_width", "kgh_solver_search_key",
-    "kgh_solver_add", "kgh_solver_add_items", "kgh_solver_found", "kgh_solver_table_size", "kgh_solver_dead_count",
+    "kgh_solver_add", "kgh_solver_add_items", "kgh_solver_found", "kgh_solver_table_size", "kgh_solver_dead_count", "kgh_solver_unstored_count",
     "kgh_solver_dump",
 ]
 
@@ -52,6 +52,7 @@ def _lib():
             "kgh_solver_found": ([V, _u64p], C.c_int),
             "kgh_solver_table_size": ([V], C.c_uint64),
             "kgh_solver_dead_count": ([V], C.c_uint64),
+            "kgh_solver_unstored_count": ([V], C.c_uint64),
             "kgh_solver_dump": ([V, _u64p, C.c_uint64], C.c_uint64),
         }
         for name, (a, r) in sig.items():
@@ -202,6 +203,12 @@ class Solver:
     @property
     def dead(self):
         return int(_lib().kgh_solver_dead_count(self._h))
+
+    @property
+    def unstored(self):
+        """Items handed in that are neither in the table nor dead (the DP that solved the key and what arrived after
+        it): table_size + dead + unstored == items handed in."""
+        return int(_lib().kgh_solver_unstored_count(self._h))
 
     def save_work(self, path, dp_bits, total_count=0, total_time=0.0, herd=None):
         """Kangaroo::SaveWork: header + DP table (+ kangaroos if herd = (px, py, d) is given)."""

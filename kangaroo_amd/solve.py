@@ -33,11 +33,14 @@ def suggested_dp(range_power, n_kangaroo):
     return max(0, int(range_power / 2.0 - math.log2(n_kangaroo) - 1))
 
 
+RING_MAX = 1 << 25  # KG_RING_MAX (engine_capi.hip): the most items one launch can return
+
+
 def _ring_safe_dp(n, nb_run):
-    """Smallest dp_bits at which one launch of n kangaroos fills at most half of the engine's DP ring (the
-    reference would exit with "items lost", engine.cu:506-510)."""
-    ring = max(65536 * 2, min(2 * n, 1 << 22))
-    return max(0, math.ceil(math.log2(n * (nb_run or 256) / (ring / 2))))
+    """Smallest dp_bits at which one launch of n kangaroos fills at most half of the largest DP ring the engine
+    allocates (the ring follows the DP size up to RING_MAX items; beyond it the reference's fate applies: "items
+    lost", engine.cu:506-510)."""
+    return max(0, math.ceil(math.log2(n * (nb_run or 256) / (RING_MAX / 2))))
 
 
 class _Search:
@@ -91,7 +94,7 @@ def _gpu_thread(st, th_id, gpu_id, grid, dp_bits, seed, nb_run, herd, keep_herd,
         eng.callKernel()
         st.started[th_id] = True
         while not st.end.is_set():
-            items = eng.Launch()
+            items = eng.Launch(copy=False)  # consumed below, before the next Launch
             st.launches[th_id] += 1
             st.dps[th_id] += len(items)
             if len(items):
@@ -206,6 +209,11 @@ def solve_key_threads(range_start, range_end, pub, gpu_ids=(0,), grid=(0, 0), dp
             if stop_after_saves is not None and saves >= stop_after_saves:
                 st.end.set()
             st.save_done.set()
+            # every parked worker must have left its wait before the next request may go out: a worker that has not
+            # yet woken would otherwise be counted as parked for the NEXT save, which would then run while that
+            # worker is already launching and inserting again
+            while st.waiting > 0 and any(t.is_alive() for t in threads):
+                time.sleep(poll / 4)
             last_save = time.perf_counter()
     st.save_done.set()
     for t in threads:  # the reference forgets to join its GPU threads; this loop does not
@@ -215,7 +223,7 @@ def solve_key_threads(range_start, range_end, pub, gpu_ids=(0,), grid=(0, 0), dp
     dt = time.perf_counter() - t0
     per = [s for s in st.stats if s]
     stats = {"kangaroos": total, "launches": sum(st.launches), "jumps": sum(s["jumps"] for s in per), "seconds": dt,
-             "dps": sum(st.dps), "table": sv.table_size, "dead": sv.dead, "dp_bits": dp_bits,
+             "dps": sum(st.dps), "table": sv.table_size, "dead": sv.dead, "unstored": sv.unstored, "dp_bits": dp_bits,
              "range_power": sv.range_power, "gpus": gpu_ids, "saves": saves, "per_thread": per,
              "device": per[0]["device"] if per else ""}
     return sv.found, stats

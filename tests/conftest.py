@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout(seconds): per-test limit (pytest-timeout, if that plugin is loaded)")
 
 
 @pytest.fixture(scope="session")
@@ -19,3 +20,13 @@ def golden():
 
     with open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")) as f:
         return json.load(f)
+
+
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of the two-rank CPU tests)."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -45,7 +45,7 @@ class OracleEngine:
     def callKernel(self):
         pass
 
-    def Launch(self, spinWait=False):
+    def Launch(self, spinWait=False, copy=True):
         dps = K.walk(self.px, self.py, self.d, self.nb_run, self.dp_mask, self.jd, self.jx, self.jy)
         self.launches += 1
         items = np.zeros(len(dps), dtype=ITEM_DTYPE)
@@ -53,7 +53,7 @@ class OracleEngine:
             items["x"][i], items["d"][i], items["kIdx"][i] = host.limbs(x), host.limbs(dd), k
         return items
 
-    def Collect(self):
+    def Collect(self, copy=True):
         return np.zeros(0, dtype=ITEM_DTYPE)
 
     def close(self):

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+from conftest import free_port
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -35,7 +37,7 @@ def test_under_a_launcher_world_must_match_gpus():
 
 def test_torchrun_style_environment_two_ranks():
     """As the driver launches it: one process per rank with RANK / WORLD_SIZE / MASTER_* set."""
-    env = dict(_clean_env(), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    env = dict(_clean_env(), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     procs = [subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--plumbing-only", "--grid", "2,2", "--steps", "5"],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True) for r in range(2)]

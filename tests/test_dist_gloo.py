@@ -3,6 +3,8 @@ max-over-ranks timing reduction."""
 import os
 import subprocess
 import sys
+
+from conftest import free_port
 import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,7 +32,7 @@ WORKER = textwrap.dedent("""
 def test_two_rank_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2")
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))

@@ -11,10 +11,10 @@ from gpu_common import dp_multiset, make_case, oracle_dps
 pytestmark = pytest.mark.gpu
 
 
-def _engine(groups, per_group, case, nb_run=None, k=None, mode=None):
+def _engine(groups, per_group, case, nb_run=None, k=None, mode=None, ring_max=0):
     from kangaroo_amd import GPUEngine
 
-    e = GPUEngine(groups, per_group, 0, 65536 * 2, mode=mode, k_per_lane=k or 0)  # kg_create_tuned
+    e = GPUEngine(groups, per_group, 0, 65536 * 2, mode=mode, k_per_lane=k or 0, ring_max=ring_max)  # kg_create_tuned
     e.SetWildOffset(case["width"] >> 1)  # core/kangaroo.cpp:436
     e.SetParams(case["dp_mask"], case["jd"], case["jx"], case["jy"])
     if nb_run:
@@ -128,7 +128,9 @@ def test_set_kangaroo_between_launches(mode):
 
 @pytest.mark.parametrize("mode", ["stream", "reg"])
 def test_dp_zero_bits_every_point_and_overflow_report(mode):
-    """dpSize = 0: every jump is a DP (core/kangaroo.cpp:110-120).  Capacity overflow is reported, not hidden."""
+    """dpSize = 0: every jump is a DP (core/kangaroo.cpp:110-120).  The DP ring follows the configuration: 262 144
+    items per launch fit although the caller's maxFound is 131 072 (the reference would exit, engine.cu:506-510).
+    With the ring capped at that maxFound the overflow is reported, not hidden."""
     from kangaroo_amd import KgError
 
     case = make_case(64, 128 * 1 * 64, seed=3, dp_bits=0)
@@ -137,12 +139,23 @@ def test_dp_zero_bits_every_point_and_overflow_report(mode):
     e.callKernel()
     assert dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 2)
     assert len(oracle_dps(case, px.copy(), py.copy(), d.copy(), 1)) == 8192
-    e.SetNbRun(64)  # 8192 * 64 = 524288 DPs > capacity 131072
+    e.SetNbRun(32)  # 8192 * 32 = 262144 DPs per launch: the ring grows to hold them (twice that + slack)
+    assert e.DpCapacity() >= 2 * 262144
     e.callKernel()
-    with pytest.raises(KgError) as ei:
-        e.Collect()
-    assert "items lost" in str(ei.value) and e.lost == 8192 * 64 - 131072
+    got = e.Launch()  # the second launch is queued into the other buffer
+    assert e.lost == 0 and len(got) == 262144
+    assert dp_multiset(got) == oracle_dps(case, px, py, d, 32)
+    got = e.Collect()
+    assert e.lost == 0 and dp_multiset(got) == oracle_dps(case, px, py, d, 32)
     e.close()
+
+    c = _engine(1, 64, case, nb_run=32, mode=mode, ring_max=131072)
+    assert c.DpCapacity() == 131072
+    c.callKernel()
+    with pytest.raises(KgError) as ei:
+        c.Collect()
+    assert "items lost" in str(ei.value) and c.lost == 8192 * 32 - 131072
+    c.close()
 
 
 def test_two_engines_in_one_process_from_two_threads():

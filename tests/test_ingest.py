@@ -60,3 +60,68 @@ def test_threaded_batch_finds_planted_key():
         items["kIdx"][pos] = kidx
     rc, _ = sv.add_items(items)
     assert rc == 2 and sv.found == priv
+
+
+def test_concurrent_producers_equal_one_by_one():
+    """Eight producer threads (one per GPU in a solve, core/kangaroo.cpp:780-786) feed ONE table at the same time, each
+    its own batches, through the solver's worker pool.  x values never repeat across producers here, so the final table
+    is independent of the interleaving and must equal the one built item by item; every item is accounted for."""
+    import threading
+
+    pub = K.ec_mul_g(0x1234567)
+    P, per_batch, batches = 8, 12000, 3
+    data = []
+    for p in range(P):
+        mine = []
+        for b in range(batches):
+            it = _items(per_batch, 100 * p + b)
+            it["x"][:, 3] = (it["x"][:, 3] & np.uint64(0x00FFFFFFFFFFFFFF)) | np.uint64((p * batches + b) << 56)  # disjoint x
+            it["x"][:, 0] ^= np.uint64(p * batches + b)  # ... also in the 128 bits the table compares
+            mine.append(it)
+        data.append(mine)
+    a = host.Solver(0, (1 << 64) - 1, pub)
+    a.set_threads(4)
+    deads = [[] for _ in range(P)]
+
+    def feed(p):
+        for it in data[p]:
+            rc, dead = a.add_items(it)
+            assert rc == 0
+            deads[p].append(dead.copy())
+
+    th = [threading.Thread(target=feed, args=(p,)) for p in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    c = host.Solver(0, (1 << 64) - 1, pub)
+    c.set_threads(1)
+    ref_dead = [[c.add_items(it)[1].copy() for it in data[p]] for p in range(P)]
+    assert a.table_size == c.table_size and a.dead == c.dead and a.unstored == c.unstored == 0
+    assert a.table_size + a.dead == P * per_batch * batches
+    assert all(np.array_equal(x, y) for p in range(P) for x, y in zip(deads[p], ref_dead[p]))
+    assert sorted(a.dump()) == sorted(c.dump())
+
+
+def test_every_item_is_accounted_for_when_the_key_is_found():
+    """table + dead + unstored == items handed in, also for the batch that solves the key and for what arrives
+    after it (threaded path and one-by-one path)."""
+    priv = 0xA5B3C1D2E7
+    pub = K.ec_mul_g(priv)
+    td = 0x3141592653
+    wd = (td - priv) % K.N
+    x = K.ec_mul_g(td)[0]
+    for n, threads in ((20000, 4), (3000, 4), (20000, 1)):
+        sv = host.Solver(0, (1 << 40) - 1, pub)
+        sv.set_threads(threads)
+        items = _items(n, 9)
+        for pos, d, kidx in ((n // 4, td, 100), (3 * n // 4, wd, 101)):
+            items["x"][pos] = [(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+            items["d"][pos] = [(d >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+            items["kIdx"][pos] = kidx
+        rc, _ = sv.add_items(items)
+        assert rc == 2 and sv.found == priv
+        assert sv.unstored >= 1 and sv.table_size + sv.dead + sv.unstored == n
+        sv.add_items(_items(500, 10))       # after the key: nothing is stored any more
+        assert sv.add(1, 2, 0) == 2
+        assert sv.table_size + sv.dead + sv.unstored == n + 501

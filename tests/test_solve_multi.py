@@ -5,6 +5,8 @@ import json
 import os
 import subprocess
 import sys
+
+from conftest import free_port
 import textwrap
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,7 +41,7 @@ WORKER = textwrap.dedent("""
 def test_two_rank_solve_with_sharded_table(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = []
@@ -81,7 +83,7 @@ FAIL_WORKER = textwrap.dedent("""
     rank, local_rank, world = dist.init(backend="gloo")
 
     class Flaky(OracleEngine):
-        def Launch(self, spinWait=False):
+        def Launch(self, spinWait=False, copy=True):
             if rank == 1 and self.launches == 2:
                 raise RuntimeError("engine failure injected on rank 1")
             return super().Launch(spinWait)
@@ -101,7 +103,7 @@ def test_failing_rank_stops_the_others_instead_of_hanging(tmp_path):
     (it would otherwise wait for ever in the next all-gather)."""
     script = tmp_path / "fail_worker.py"
     script.write_text(FAIL_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = [p.communicate(timeout=120) for p in procs]

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from kernel_resources import LLVM, extract_code_object  # noqa: E402
 
 lib = sys.argv[1] if len(sys.argv) > 1 else "kangaroo_amd/libkangaroo_amd.so"
-want = sys.argv[2] if len(sys.argv) > 2 else "kg_walk_kernel_stream<3"
+want = sys.argv[2] if len(sys.argv) > 2 else "kg_walk_kernel_stream<2"
 co = "/tmp/kg_loop_mix.co"
 extract_code_object(lib, co)
 dis = subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", "-C", co], text=True)
