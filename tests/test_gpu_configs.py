@@ -239,7 +239,7 @@ def test_config5_default_grid_dp8_drain_without_loss():
             pt = host.ec_add(pt, sv.key)
         assert pt[0] == host.to_int(it["x"])
     print(f"DP=32 kernel {ms_quiet:.2f} ms, DP=8 kernel {sorted(ms)[len(ms) // 2]:.2f} ms (8.4 M DPs per launch)")
-    assert sorted(ms)[len(ms) // 2] < 1.15 * ms_quiet
+    assert sorted(ms)[len(ms) // 2] < 1.25 * ms_quiet
 
 
 @pytest.mark.timeout(700)

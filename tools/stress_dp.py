@@ -31,8 +31,10 @@ t0 = time.perf_counter()
 n_dp = 0
 t_ins = 0.0
 dead_total = 0
+kernel_ms = []
 for i in range(launches):
-    items = eng.Launch()
+    items = eng.Launch(copy=False)
+    kernel_ms.append(eng.LastKernelMs())
     n_dp += len(items)
     t1 = time.perf_counter()
     rc, dead = sv.add_items(items)
@@ -46,7 +48,7 @@ eng.Collect()
 dt = time.perf_counter() - t0
 print(f"{eng.deviceName} {eng.KernelName()} kangaroos={n} dp_bits={dp_bits} launches={launches}")
 print(f"jumps/s (wall, host ingest in the loop) : {n * 256 * launches / dt / 1e9:.2f} G")
-print(f"kernel ms per launch                    : {eng.LastKernelMs():.1f}")
+print(f"kernel ms per launch (walk + history sum): median {sorted(kernel_ms)[len(kernel_ms) // 2]:.2f}, min {min(kernel_ms):.2f}, max {max(kernel_ms):.2f}")
 print(f"DPs drained                             : {n_dp} = {n_dp / dt / 1e6:.2f} M/s, lost {eng.lost}")
 print(f"table insert rate (add_items only)      : {n_dp / t_ins / 1e6:.2f} M/s, table {sv.table_size}, dead {dead_total}")
 eng.close()
