@@ -23,28 +23,51 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 MAD32_PER_JUMP = 416          # 5 modmul * 74 + 1 modsqr * 46, inversion excluded
-# v_mad_u64_u32: 5.08 cycles per wave64 per SIMD measured at 4 waves per SIMD (profiles/ubench_instr_table_r01.txt:96)
-# -> 1024 SIMDs * 64 lanes / 5.08 cycles * 2.4 GHz = 30.96 T MAD32/s
-MAD_CYCLES_PER_WAVE = 5.08
-PEAK_MAD32_PER_S = 1024 * 64 / MAD_CYCLES_PER_WAVE * 2.4e9
+# Peak of record (the measured micro-benchmark is the denominator): the best SUSTAINED v_mad_u64_u32 rate
+# measured on this chip, 540.8 G wave-instructions/s over 0.7 s at two waves per SIMD and a measured 2382 MHz
+# (profiles/r02_ubench_power.txt:4, tools/ubench_power.hip) = 34.6 T MAD32/s = 4.51 cycles per wave64 and SIMD.
+PEAK_WAVE_MADS_PER_S = 540.8e9
+PEAK_MAD32_PER_S = PEAK_WAVE_MADS_PER_S * 64
+MAD_CYCLES_PER_WAVE = 1024 * 2.382e9 / PEAK_WAVE_MADS_PER_S   # 4.51
+# Round 1's short run (1.1 ms, 4 waves per SIMD, assumed 2.4 GHz): 5.08 cycles -> 30.96 T MAD32/s; kept beside it, labelled
+PEAK_MAD32_R01 = 1024 * 64 / 5.08 * 2.4e9
+# v_mad_u64_u32 the kernel really issues per jump and lane with 9x29-bit limbs: 5.5 multiplications x 101 + 1 squaring x
+# 65 + the shared inversion's share (one inversion + 9 multiplications per 4 waves x K jumps) ~ 5  (DESIGN.md section 4;
+# static counts from tools/loop_mix.py, total VALU per jump from the PMC pass in profiles/)
+MADS_ISSUED_PER_JUMP = 626
 STATE_BYTES_PER_KANGAROO = 192  # 96 B loaded + 96 B stored per launch
 
 
 def cpu_model():
+    """Model string of the host CPU: "model name" of /proc/cpuinfo plus family / model / stepping (some hosts of the
+    pool report a bare vendor string as the name) and the logical CPUs this process may use."""
+    want = ("model name", "vendor_id", "cpu family", "model", "stepping")
+    got = {}
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
+                k, _, v = line.partition(":")
+                k = k.strip()
+                if k in want and k not in got:
+                    got[k] = v.strip()
+                if len(got) == len(want):
+                    break
     except OSError:
         pass
-    return "unknown"
+    if not got:
+        return "unknown"
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 0
+    return (f"{got.get('model name', '?')} ({got.get('vendor_id', '?')} family {got.get('cpu family', '?')} model "
+            f"{got.get('model', '?')} stepping {got.get('stepping', '?')}; {usable} of {os.cpu_count()} logical CPUs usable)")
 
 
-def cpu_baseline(seconds_target=10.0):
+def cpu_baseline(seconds_all=30.0, seconds_one=5.0):
     """Oracle (CPU port of SolveKeyCPU's loop) on the host cores: 1024 kangaroos per thread as the
     reference's CPU_GRP_SIZE, same 125-bit jump table.  Bounded sample; reported, never the target.
-    Two figures as SURVEY §8d asks: all the threads the box gives one GPU (16) and one thread."""
+    Two figures as SURVEY §8d asks: all the threads the box gives one GPU (16), >= 30 s, and one thread, >= 5 s."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import kgoracle as K
 
@@ -54,42 +77,52 @@ def cpu_baseline(seconds_target=10.0):
     key = K.ec_mul_g(0xA5B3C1D2E7)
     width = (1 << 125) - 1
     herds = [K.create_herd(rng, 125, width, key, 1024, 0) for _ in range(cores)]
-    # calibrate on one thread
-    t0 = time.time()
-    K.walk_raw(*herds[0], 60, 0xFFFFFFFF00000000, jd, jx, jy, 16)
-    per_step = (time.time() - t0) / 60
-    one_thread = 1024 / per_step
-    steps = max(50, int(seconds_target / per_step))
+    mask = 0xFFFFFFFF00000000
+    # calibrate (short), then the one-thread figure over >= seconds_one
+    t0 = time.perf_counter()
+    K.walk_raw(*herds[0], 60, mask, jd, jx, jy, 16)
+    per_step = (time.perf_counter() - t0) / 60
+    steps_one = max(200, int(seconds_one / per_step) + 1)
+    t0 = time.perf_counter()
+    K.walk_raw(*herds[0], steps_one, mask, jd, jx, jy, 16)
+    dt_one = time.perf_counter() - t0
+    one_thread = 1024 * steps_one / dt_one
+    steps = max(200, int(seconds_all / (dt_one / steps_one) * 1.05) + 1)  # threads share cores' turbo: a little longer
 
     def work(h):
-        K.walk_raw(h[0], h[1], h[2], steps, 0xFFFFFFFF00000000, jd, jx, jy, 16)
+        K.walk_raw(h[0], h[1], h[2], steps, mask, jd, jx, jy, 16)
 
     th = [threading.Thread(target=work, args=(h,)) for h in herds]
-    t0 = time.time()
+    t0 = time.perf_counter()
     for t in th:
         t.start()
     for t in th:
         t.join()
-    dt = time.time() - t0
+    dt = time.perf_counter() - t0
     jumps = cores * 1024 * steps
     return {"value": jumps / dt, "unit": "jumps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "value_1thread": one_thread,
+            "value_1thread": one_thread, "seconds": dt, "seconds_1thread": dt_one,
             "sample": f"{cores} threads x 1024 kangaroos x {steps} steps, 125-bit range, oracle/kg_oracle.c ({dt:.1f} s); "
-                      f"1 thread: 1024 kangaroos x 60 steps"}
+                      f"1 thread: 1024 kangaroos x {steps_one} steps ({dt_one:.1f} s)"}
 
 
 class PowerSampler:
-    """Board power of the first amdgpu hwmon device, sampled every 50 ms in a thread (read-only sysfs).  The jump
-    kernel runs at the board's power cap; the line reports what was drawn."""
+    """Board power of the GPU this rank drives, sampled every 50 ms in a thread (read-only sysfs).  The hwmon entry is
+    the one whose PCI device is the engine's (kg_device_pci_bus_id): DRM card order need not be HIP device order.  The
+    jump kernel runs at the board's power cap; the line reports what was drawn."""
 
-    def __init__(self):
+    def __init__(self, pci_bus_id=None):
         import glob
 
-        self.path = self.cap = None
+        self.path = self.cap = self.card = None
         for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            dev = os.path.basename(os.path.realpath(os.path.join(d, "..", "..")))  # .../0000:c1:00.0
+            if pci_bus_id and dev.lower() != pci_bus_id.lower():
+                continue
             for leaf in ("power1_average", "power1_input"):
                 if os.path.exists(os.path.join(d, leaf)):
                     self.path = os.path.join(d, leaf)
+                    self.card = dev
                     try:
                         self.cap = int(open(os.path.join(d, "power1_cap")).read()) * 1e-6
                     except (OSError, ValueError):
@@ -123,7 +156,8 @@ class PowerSampler:
         if not self.samples:
             return None
         v = sorted(self.samples)
-        return {"median_W": v[len(v) // 2], "max_W": v[-1], "cap_W": self.cap, "samples": len(v)}
+        return {"median_W": v[len(v) // 2], "max_W": v[-1], "cap_W": self.cap, "samples": len(v), "pci": self.card,
+                "sysfs": self.path}
 
 
 def launch_ranks(n, argv):
@@ -266,9 +300,12 @@ def main():
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     kernel_ms, clock_mhz = [], []
     n_dp = 0
-    power = PowerSampler() if world == 1 else None
-    if power:
-        power.start()
+    try:
+        pci = GPUEngine.PciBusId(gpu_id)
+    except Exception:  # noqa: BLE001 — power evidence is optional
+        pci = None
+    power = PowerSampler(pci)  # every rank samples its own board
+    power.start()
     t0 = time.perf_counter()
     eng.callKernel()
     for _ in range(args.steps - 1):
@@ -281,9 +318,12 @@ def main():
     torch.cuda.synchronize() if torch.cuda.is_available() else None
     dist.barrier()
     elapsed = time.perf_counter() - t0
-    board_power = power.stop() if power else None
+    board_power = power.stop()
     elapsed = dist.max_over_ranks(elapsed)
     total_kangaroos = dist.sum_over_ranks(n)
+    # median board power of every rank's own GPU (0 where sysfs gave nothing)
+    power_per_rank = [float(v[0]) * 1e-3 for v in
+                      dist.all_gather_array(np.array([int(1e3 * board_power["median_W"]) if board_power else 0], dtype=np.uint64))]
 
     # self-check, outside the timed region: a sample of the herd must still satisfy P_i = d_i*G (+ key for the
     # wild, odd-indexed half) after all the jumps; host EC code of the product library, not the oracle
@@ -315,7 +355,7 @@ def main():
     # profiles/r01_pmc_hbm.json and DESIGN.md "Measurement"); only quoted when the launch shape is the one profiled
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_hbm.json")) as f:
             pmc = json.load(f)
         if pmc["kangaroos_per_gpu"] == n and pmc["nb_run"] == args.nb_run and pmc["kernel"] == eng.KernelName():
             traffic = pmc["hbm_bytes_per_launch"]
@@ -346,18 +386,27 @@ def main():
                                   "sampled_per_gpu": args.check, "bad": 0}},
         "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MAD32_PER_S / 1e12,
                      "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_PER_S, "traffic": traffic,
+                     "traffic_source": "profiles/r03_pmc_hbm.json (rocprofv3 --pmc passes over this command, not measured in this run)"
+                     if traffic else None,
                      "kernel": eng.KernelName(), "kernel_ms_avg": avg_kernel_ms,
                      "kernel_ms_median": float(np.median(kernel_ms)),
-                     "shader_clock_mhz": clk, "peak_at_shader_clock": peak_at_clk / 1e12 if peak_at_clk else None,
+                     "mad_issue_frac": kernel_jumps_per_s * MADS_ISSUED_PER_JUMP / PEAK_MAD32_PER_S,
+                     "mads_issued_per_jump": MADS_ISSUED_PER_JUMP,
+                     "shader_clock_mhz": clk if clk else "n/a (register-resident kernel has no clock stamps)",
+                     "peak_at_shader_clock": peak_at_clk / 1e12 if peak_at_clk else None,
                      "frac_at_shader_clock": achieved / peak_at_clk if peak_at_clk else None,
-                     "board_power": board_power,
+                     "peak_r01_short_run": PEAK_MAD32_R01 / 1e12, "frac_vs_peak_r01_short_run": achieved / PEAK_MAD32_R01,
+                     "board_power": board_power, "board_power_median_W_per_rank": power_per_rank,
                      "mad32_per_jump": MAD32_PER_JUMP, "kernel_jumps_per_s": kernel_jumps_per_s,
                      "hbm": {"bytes_per_jump": bytes_per_jump, "achieved_GBps": hbm_gbps, "peak_GBps": 8000.0,
                              "frac": hbm_gbps / 8000.0},
-                     "note": "primary bound per SURVEY §8d is VALU integer multiply issue: peak = 1024 SIMDs x 64 lanes / 5.08 "
-                             "cycles x 2.4 GHz (measured issue rate, nominal clock); frac_at_shader_clock uses the clock the "
-                             "kernel ran at.  The streaming kernel also moves bytes_per_jump through HBM, see hbm.frac; "
-                             "traffic = PMC HBM bytes per launch (profiles/)"},
+                     "note": "bound per SURVEY §8d is VALU integer multiply issue.  peak = best sustained measured v_mad_u64_u32 "
+                             "rate (540.8 G wave-instr/s x 64 lanes at a measured 2382 MHz, profiles/r02_ubench_power.txt); frac = "
+                             "algorithmic 416 MAD32/jump over that peak; mad_issue_frac = the 626 multiply-adds the 9x29-limb "
+                             "kernel really issues per jump over the same peak; frac_at_shader_clock scales the peak to the "
+                             "clock the kernel ran at (informative); peak_r01_short_run is round 1's 1 ms measurement.  The "
+                             "streaming kernel also moves bytes_per_jump through HBM, see hbm.frac; traffic = PMC HBM bytes "
+                             "per launch (profiles/)"},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -176,6 +176,9 @@ int kg_field_kat(int gpu_id, int op, const uint32_t *a, const uint32_t *b, const
 /* Replaces GPUEngine::AllocatePinnedMemory / FreePinnedMemory (engine.cu:221-233). */
 void *kg_alloc_pinned(size_t size);
 void kg_free_pinned(void *p);
+/* PCI address of device gpu_id as "dddd:bb:dd.f" (what PrintCudaInfo's cudaDeviceProp carries, engine.cu:249-262):
+ * lets a caller find the device's sysfs entry (power, clocks) without assuming that DRM card order is HIP order. */
+int kg_device_pci_bus_id(int gpu_id, char *buf, size_t buflen);
 /* Replaces GPUEngine::PrintCudaInfo (engine.cu:235-275): one line per device on stdout. */
 int kg_print_device_info(void);
 

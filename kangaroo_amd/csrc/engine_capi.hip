@@ -191,6 +191,15 @@ extern "C" int kg_default_grid(int gpu_id, int *x, int *y) {
   return KG_OK;
 }
 
+extern "C" int kg_device_pci_bus_id(int gpu_id, char *buf, size_t buflen) {
+  if (!buf || buflen < 13) return fail(KG_ERR_ARG, "kg_device_pci_bus_id: buffer of at least 13 bytes needed");
+  int c = 0;
+  if (kg_device_count(&c) != KG_OK) return KG_ERR_HIP;
+  if (gpu_id < 0 || gpu_id >= c) return fail(KG_ERR_ARG, "kg_device_pci_bus_id: invalid gpuId");
+  HIPCHK(hipDeviceGetPCIBusId(buf, (int)buflen, gpu_id));
+  return KG_OK;
+}
+
 extern "C" int kg_print_device_info(void) {
   int c = 0;
   if (kg_device_count(&c) != KG_OK) return KG_ERR_HIP;

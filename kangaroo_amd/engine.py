@@ -89,6 +89,7 @@ def load_library():
         "kg_alloc_pinned": ([C.c_size_t], C.c_void_p),
         "kg_free_pinned": ([C.c_void_p], None),
         "kg_print_device_info": ([], C.c_int),
+        "kg_device_pci_bus_id": ([C.c_int, C.c_char_p, C.c_size_t], C.c_int),
         "kg_last_error": ([], C.c_char_p),
         "kg_version": ([], C.c_char_p),
     }
@@ -105,7 +106,7 @@ ABI_SYMBOLS = [
     "kg_nb_thread", "kg_group_size", "kg_nb_kangaroo", "kg_set_wild_offset", "kg_set_params", "kg_set_kangaroos",
     "kg_get_kangaroos", "kg_herd_from_distances", "kg_set_kangaroo", "kg_set_nb_run", "kg_kick", "kg_kick_static", "kg_collect", "kg_launch",
     "kg_kick_and_wait", "kg_dp_capacity", "kg_last_kernel_ms", "kg_last_kernel_clock", "kg_kernel_info", "kg_kernel_name", "kg_field_kat", "kg_alloc_pinned", "kg_free_pinned",
-    "kg_print_device_info", "kg_last_error", "kg_version",
+    "kg_print_device_info", "kg_device_pci_bus_id", "kg_last_error", "kg_version",
 ]
 
 
@@ -175,6 +176,13 @@ class GPUEngine:
     @staticmethod
     def PrintCudaInfo():
         _chk(load_library().kg_print_device_info())
+
+    @staticmethod
+    def PciBusId(gpuId):
+        """PCI address of the device ("0000:c1:00.0"), kg_device_pci_bus_id."""
+        buf = C.create_string_buffer(32)
+        _chk(load_library().kg_device_pci_bus_id(gpuId, buf, 32))
+        return buf.value.decode().lower()
 
     @staticmethod
     def DeviceCount():
