@@ -137,8 +137,10 @@ int kg_kick_static(kg_engine *e);
  * its DPs.  *n receives the item count stored (<= cap).  If the launch produced more than the
  * engine's buffer or cap can hold, returns KG_ERR_LOST with *lost = number dropped. */
 int kg_collect(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *n, uint32_t *lost);
-/* GPUEngine::Launch (engine.cu:486-539): collect the launch in flight, start the next one. The
- * next launch is queued before the items are unpacked, so host work overlaps the GPU. */
+/* GPUEngine::Launch (engine.cu:486-539): collect the launch in flight, start the next one.  The next launch is
+ * queued BEFORE the call waits for the one in flight (two launch buffers), so the GPU goes from one walk kernel
+ * straight into the next and host work overlaps it.  As in the reference, when the call returns the next launch is
+ * already under way: a kg_set_kangaroo issued now takes effect for the launch after that one. */
 int kg_launch(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *n, uint32_t *lost);
 /* Items one launch can return: the capacity kg_collect / kg_launch need in `items` to take everything the DP ring
  * holds under the current configuration (it follows kg_set_params / kg_set_nb_run).  The reference's counterpart is
@@ -148,9 +150,12 @@ int kg_dp_capacity(const kg_engine *e, uint32_t *items);
  * next kg_collect. */
 int kg_kick_and_wait(kg_engine *e);
 
-/* Duration in milliseconds of the last completed launch's kernel, measured with HIP events on the
+/* Duration in milliseconds of the last completed launch's walk kernel, measured with HIP events on the
  * engine's stream (bench.py's roofline figure).  No counterpart in the reference. */
 int kg_last_kernel_ms(const kg_engine *e, float *ms);
+/* The same for the launch's history kernel (distance sums and the distances of the launch's DP items), which runs on
+ * the engine's second stream underneath the next launch's walk kernel; 0 for the register-resident kernel. */
+int kg_last_sum_kernel_ms(const kg_engine *e, float *ms);
 /* Clock the last completed launch of the streaming kernel really ran at: shader clock cycles and ticks of the
  * constant 100 MHz reference counter between the start and the end of workgroup 0 (s_memtime / s_memrealtime);
  * MHz = 100 * cycles / ticks.  Zeros for the register-resident kernel.  No counterpart in the reference. */

@@ -2,8 +2,10 @@
 //
 // Host half of the drop-in for the reference's GPUEngine (math/gpu/engine.cu).  Differences that
 // are deliberate and MI355X-first:
-//   * one private stream per engine, two DP buffers: launch i+1 is queued before the DPs of
-//     launch i are unpacked (the reference re-launches only after unpacking, engine.cu:515-538);
+//   * two private streams per engine and two sets of launch buffers (DP ring, jump-index history, DP chains):
+//     kg_launch queues launch i+1 BEFORE it waits for launch i, so the GPU never idles between launches, and the
+//     history kernel of launch i (distances, DP distances, the PCIe writes of the items) runs on the second stream
+//     underneath the walk kernel of launch i+1 (the reference re-launches only after unpacking, engine.cu:515-538);
 //   * DP items land directly in host-visible pinned memory; only the 4-byte counter is copied;
 //   * the herd is stored as 12 lane-contiguous uint64 planes indexed by host kangaroo index
 //     (no per-block pinned repacking loop as in engine.cu:289-320);
@@ -93,12 +95,18 @@ struct kg_engine {
   bool fell_back = false;     // streaming was wanted but the herd is beyond its 4 GiB workspace limit
   u32 *ws = nullptr;          // its workspace
   size_t ws_bytes = 0;
+  size_t ws_laid_out = 0;     // stream_ws_need the current layout of ws was computed for
   u32 nb_run = KG_NB_RUN;
   u32 max_found = 0;          // the caller's hint (core/kangaroo.cpp:408), floor of the ring capacity
   u32 ring_cap[2] = {0, 0};   // items each DP buffer holds
   u32 ring_max = 0;           // upper bound of the ring (kg_tuning.ring_max_items or KG_RING_MAX)
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // walk kernels, herd upload / download
+  hipStream_t stream2 = nullptr;  // streaming kernel only: kg_hist_sum_kernel, SetKangaroo pokes, the launch's copies
   hipEvent_t ev_start[2] = {nullptr, nullptr}, ev_stop[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_sum0[2] = {nullptr, nullptr}, ev_sum1[2] = {nullptr, nullptr};  // around kg_hist_sum_kernel
+  hipEvent_t ev_walk[2] = {nullptr, nullptr};  // walk kernel finished, clock stamps copied (stream2 waits for it)
+  hipEvent_t ev_poke = nullptr;   // after the last SetKangaroo poke queued on stream2
+  bool pokes_queued = false;      // pokes on stream2 that the next walk kernel must wait for
   u64 *X = nullptr, *Y = nullptr, *D = nullptr;
   JumpTableDev *jt = nullptr;
   DpItemDev *out_host[2] = {nullptr, nullptr};
@@ -111,9 +119,10 @@ struct kg_engine {
   u64 dp_mask = 0;
   int max_jd_bits = 0;
   bool params_set = false, herd_set = false;
-  int inflight = -1, next_buf = 0;
+  int q[2] = {-1, -1}, qn = 0;  // launch buffers in flight, oldest first (kg_launch keeps two queued)
+  int next_buf = 0;
   int pending = -1;  // completed by kick_and_wait, not yet collected
-  float last_ms = 0.f;
+  float last_ms = 0.f, last_sum_ms = 0.f;
   u64 last_clk = 0, last_ref = 0;  // shader cycles and 100 MHz reference ticks of the last streaming launch (workgroup 0)
   int cus = 0;
   char name[256] = {0};
@@ -250,6 +259,13 @@ static int scratch_lookup(int gpu) {
   return KG_OK;
 }
 
+// both of the engine's streams idle
+static int sync_streams(kg_engine *e) {
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->stream2) HIPCHK(hipStreamSynchronize(e->stream2));
+  return KG_OK;
+}
+
 // ---- DP ring ------------------------------------------------------------------------------------------
 // Two host-pinned buffers the kernels append distinguished points to.  The reference sizes its buffer from the
 // caller's maxFound alone and exits when a launch produces more (math/gpu/engine.cu:99,506-510; core/kangaroo.cpp:408
@@ -287,14 +303,14 @@ static int ring_alloc(kg_engine *e, int b, u32 items) {
 static int ring_ensure(kg_engine *e, int b) {
   const u32 want = ring_want(e);
   if (e->ring_cap[b] >= want) return KG_OK;
-  HIPCHK(hipStreamSynchronize(e->stream));
+  if (sync_streams(e) != KG_OK) return KG_ERR_HIP;
   return ring_alloc(e, b, want);
 }
 
 // after kg_set_params / kg_set_nb_run: grow both buffers now if no launch is in flight or waiting to be collected
 // (otherwise kg_kick grows the buffer it is about to use)
 static int ring_follow_config(kg_engine *e) {
-  if (e->inflight >= 0 || e->pending >= 0) return KG_OK;
+  if (e->qn > 0 || e->pending >= 0) return KG_OK;
   for (int b = 0; b < 2; ++b) {
     const int rc = ring_ensure(e, b);
     if (rc != KG_OK) return rc;
@@ -302,21 +318,44 @@ static int ring_follow_config(kg_engine *e) {
   return KG_OK;
 }
 
-// bytes of the streaming kernel's launch-time workspace: slots, jump-index history, pacing table (+ clock stamps),
-// then the DP chains: one head per kangaroo slot and one link per ring item (walk_kernel_stream.h)
+// The streaming kernel's launch-time workspace: the kangaroo slots and the pacing table (+ clock stamps) once, and
+// per launch buffer (`nbuf` of them) the jump-index history and the DP chains (one head per kangaroo slot, one link
+// per ring item; walk_kernel_stream.h).  kg_kick / kg_launch use two launch buffers, so that the history kernel of one
+// launch can run underneath the walk kernel of the next; kg_kick_static uses one.
 static size_t stream_ws_part(const kg_engine *e) {
   return (size_t)WS_SLOT_WORDS * (size_t)e->K * (size_t)e->threads * sizeof(u32);
 }
-static size_t stream_hist_part(const kg_engine *e) {  // 16-byte aligned: the pacing table sits behind it
+static size_t stream_hist_part(const kg_engine *e) {  // 16-byte aligned
   return ((size_t)e->nb_run * (size_t)e->K * (size_t)e->threads + 15) & ~(size_t)15;
 }
 static size_t stream_pace_part() { return (size_t)(PACE_KEYS * 4 + PACE_TAIL) * sizeof(u32); }  // a multiple of 16
 static size_t stream_head_part(const kg_engine *e) { return (size_t)e->cap * sizeof(u32); }     // cap is a multiple of 256
-static size_t stream_link_part(const kg_engine *e) {
-  return (size_t)std::max(e->ring_cap[0], e->ring_cap[1]) * sizeof(DpLink);
+static size_t stream_link_part(const kg_engine *e) {                                             // 16-byte aligned
+  return ((size_t)std::max(e->ring_cap[0], e->ring_cap[1]) * sizeof(DpLink) + 15) & ~(size_t)15;
 }
-static size_t stream_ws_need(const kg_engine *e) {
-  return stream_ws_part(e) + stream_hist_part(e) + stream_pace_part() + stream_head_part(e) + stream_link_part(e);
+static size_t stream_ws_need(const kg_engine *e, int nbuf) {
+  return stream_ws_part(e) + stream_pace_part() +
+         (size_t)nbuf * (stream_hist_part(e) + stream_head_part(e) + stream_link_part(e));
+}
+struct StreamWs {
+  u32 *slots, *pace, *dp_head;
+  unsigned char *hist;
+  DpLink *dp_link;
+};
+// pointers of launch buffer hb (< nbuf) inside a workspace laid out for nbuf buffers
+static StreamWs stream_ws_at(const kg_engine *e, void *ws, int nbuf, int hb) {
+  unsigned char *p = (unsigned char *)ws;
+  StreamWs w;
+  w.slots = (u32 *)p;
+  p += stream_ws_part(e);
+  w.pace = (u32 *)p;
+  p += stream_pace_part();
+  w.hist = p + (size_t)hb * stream_hist_part(e);
+  p += (size_t)nbuf * stream_hist_part(e);
+  w.dp_head = (u32 *)(p + (size_t)hb * stream_head_part(e));
+  p += (size_t)nbuf * stream_head_part(e);
+  w.dp_link = (DpLink *)(p + (size_t)hb * stream_link_part(e));
+  return w;
 }
 
 // ---- lifetime ---------------------------------------------------------------------------------------
@@ -329,7 +368,12 @@ extern "C" int kg_destroy(kg_engine *e) {
   if (!e) return KG_OK;
   (void)hipSetDevice(e->gpu);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->stream2) (void)hipStreamSynchronize(e->stream2);
+  if (e->ev_poke) (void)hipEventDestroy(e->ev_poke);
   for (int b = 0; b < 2; ++b) {
+    if (e->ev_walk[b]) (void)hipEventDestroy(e->ev_walk[b]);
+    if (e->ev_sum0[b]) (void)hipEventDestroy(e->ev_sum0[b]);
+    if (e->ev_sum1[b]) (void)hipEventDestroy(e->ev_sum1[b]);
     if (e->ev_start[b]) (void)hipEventDestroy(e->ev_start[b]);
     if (e->ev_stop[b]) (void)hipEventDestroy(e->ev_stop[b]);
     if (e->ev_done[b]) (void)hipEventDestroy(e->ev_done[b]);
@@ -344,6 +388,7 @@ extern "C" int kg_destroy(kg_engine *e) {
   if (e->stage) (void)hipHostFree(e->stage);
   if (e->ws) (void)hipFree(e->ws);
   if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->stream2) (void)hipStreamDestroy(e->stream2);
   delete e;
   return KG_OK;
 }
@@ -434,7 +479,14 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
     }                                                                                   \
   } while (0)
   CRT(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  if (e->streaming) {
+    CRT(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+    CRT(hipEventCreateWithFlags(&e->ev_poke, hipEventDisableTiming));
+  }
   for (int b = 0; b < 2; ++b) {
+    CRT(hipEventCreateWithFlags(&e->ev_walk[b], hipEventDisableTiming));
+    CRT(hipEventCreate(&e->ev_sum0[b]));
+    CRT(hipEventCreate(&e->ev_sum1[b]));
     CRT(hipEventCreate(&e->ev_start[b]));
     CRT(hipEventCreate(&e->ev_stop[b]));
     CRT(hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
@@ -475,7 +527,7 @@ extern "C" int kg_device_name(const kg_engine *e, char *buf, size_t buflen) {
 extern "C" int kg_memory_bytes(const kg_engine *e, uint64_t *bytes) {
   if (!e || !bytes) return fail(KG_ERR_ARG, "kg_memory_bytes: bad argument");
   u64 b = (u64)e->cap * 12 * sizeof(u64) + ((u64)e->ring_cap[0] + e->ring_cap[1]) * sizeof(DpItemDev) + sizeof(JumpTableDev);
-  if (e->streaming) b += stream_ws_need(e);  // slots, jump-index history, pacing table, DP chains
+  if (e->streaming) b += stream_ws_need(e, 2);  // slots, pacing table, two sets of jump-index history and DP chains
   *bytes = b;
   return KG_OK;
 }
@@ -534,7 +586,8 @@ extern "C" int kg_set_params(kg_engine *e, uint64_t dp_mask, const uint64_t *jd,
     e->max_jd_bits = std::max(e->max_jd_bits, bit_length256(jd + 4 * i));
   }
   e->dp_mask = dp_mask;
-  // ordered on the engine's stream behind any launch in flight
+  // behind any launch in flight: its walk kernel (stream) and its history kernel (stream2) both read the table
+  if (sync_streams(e) != KG_OK) return KG_ERR_HIP;
   HIPCHK(hipMemcpyAsync(e->jt, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->params_set = true;
@@ -542,10 +595,7 @@ extern "C" int kg_set_params(kg_engine *e, uint64_t dp_mask, const uint64_t *jd,
 }
 
 // ---- herd upload / download --------------------------------------------------------------------------
-static int wait_idle(kg_engine *e) {
-  HIPCHK(hipStreamSynchronize(e->stream));
-  return KG_OK;
-}
+static int wait_idle(kg_engine *e) { return sync_streams(e); }
 
 extern "C" int kg_set_kangaroos(kg_engine *e, const uint64_t *px, const uint64_t *py, const uint64_t *d, uint64_t n) {
   if (!e || !px || !py || !d) return fail(KG_ERR_ARG, "kg_set_kangaroos: bad argument");
@@ -721,26 +771,34 @@ extern "C" int kg_set_kangaroo(kg_engine *e, uint64_t k_idx, const uint64_t px[4
   u64 dd[4];
   if (k_idx & 1) order_add(dd, d, e->wild);  // engine.cu:414-416
   else memcpy(dd, d, 32);
-  hipLaunchKernelGGL(kg_poke_kernel, dim3(1), dim3(1), 0, e->stream, e->X, e->Y, e->D, e->cap, (u64)k_idx, px[0],
+  // Streaming kernel: the poke goes behind the history kernel of the newest launch queued (stream2 is in order, and
+  // that kernel starts only after its walk kernel): the launch's epilogue has written X / Y and its history sum has
+  // been added to D by then.  The next walk kernel waits for the poke (launch_walk).
+  hipStream_t st = e->stream2 ? e->stream2 : e->stream;
+  hipLaunchKernelGGL(kg_poke_kernel, dim3(1), dim3(1), 0, st, e->X, e->Y, e->D, e->cap, (u64)k_idx, px[0],
                      px[1], px[2], px[3], py[0], py[1], py[2], py[3], dd[0], dd[1], dd[2], dd[3]);
   HIPCHK(hipGetLastError());
+  if (e->stream2) e->pokes_queued = true;
   return KG_OK;
 }
 
 // ---- launch / collect ------------------------------------------------------------------------------------
-static int kick_checks(kg_engine *e) {
+// depth: launches that may already be in flight (0 for the public kg_kick, 1 for the kick inside kg_launch)
+static int kick_checks(kg_engine *e, int depth) {
   if (!e) return fail(KG_ERR_ARG, "kg_kick: null engine");
   if (!e->params_set || !e->herd_set) return fail(KG_ERR_STATE, "GPUEngine: Kernel: SetParams/SetKangaroos not called");
-  if (e->inflight >= 0) return fail(KG_ERR_STATE, "GPUEngine: Kernel: a launch is already in flight");
+  if (e->qn > depth) return fail(KG_ERR_STATE, "GPUEngine: Kernel: a launch is already in flight");
   if (e->pending >= 0) return fail(KG_ERR_STATE, "GPUEngine: Kernel: previous launch not collected");
   if (bind(e) != KG_OK) return KG_ERR_HIP;
   e->DW = pick_delta_words(e);
   return KG_OK;
 }
 
-// Queue one launch on the engine's stream.  ws: workspace of the streaming kernel (stream_ws_need bytes), unused
-// by the register-resident kernels.  Allocates nothing.
-static int launch_walk(kg_engine *e, void *ws) {
+// Queue one launch into launch buffer next_buf.  ws: workspace of the streaming kernel laid out for nbuf launch
+// buffers (stream_ws_need bytes), unused by the register-resident kernels.  Streaming kernel: the walk kernel goes to
+// `stream`, the history kernel and the launch's last copies to `stream2` behind an event, so that with two launch
+// buffers they run underneath the NEXT walk kernel.  Allocates nothing.
+static int launch_walk(kg_engine *e, void *ws, int nbuf) {
   const Variant *v = e->streaming ? nullptr : find_variant(e->K, e->DW);
   if (!v && !e->streaming) return fail(KG_ERR_STATE, "GPUEngine: Kernel: no kernel variant for this configuration");
   const int b = e->next_buf;
@@ -763,79 +821,97 @@ static int launch_walk(kg_engine *e, void *ws) {
     const void *fn = e->streaming ? (const void *)g_stream_fn : (const void *)v->fn;
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  HIPCHK(hipMemsetAsync(e->count_dev + b, 0, sizeof(u32), e->stream));
-  HIPCHK(hipEventRecord(e->ev_start[b], e->stream));
-  unsigned char *base = (unsigned char *)ws;
-  u32 *pace = nullptr;
+  hipStream_t sA = e->stream;
+  hipStream_t sB = e->streaming ? e->stream2 : e->stream;  // where the launch is finished
+  if (e->pokes_queued) {
+    // SetKangaroo pokes sit on stream2 behind the previous launch's history kernel: this walk must see them
+    HIPCHK(hipEventRecord(e->ev_poke, e->stream2));
+    HIPCHK(hipStreamWaitEvent(sA, e->ev_poke, 0));
+    e->pokes_queued = false;
+  }
+  HIPCHK(hipMemsetAsync(e->count_dev + b, 0, sizeof(u32), sA));
   if (e->streaming) {
+    const StreamWs w = stream_ws_at(e, ws, nbuf, nbuf > 1 ? b : 0);
     StreamArgs sa;
     sa.a = a;
-    sa.ws = (u32 *)ws;
-    sa.hist = base + stream_ws_part(e);
+    sa.ws = w.slots;
+    sa.hist = w.hist;
     sa.K = (u32)e->K;
-    pace = (u32 *)(sa.hist + stream_hist_part(e));
-    sa.pace = pace;
-    sa.dp_head = (u32 *)((unsigned char *)pace + stream_pace_part());
-    sa.dp_link = (DpLink *)((unsigned char *)sa.dp_head + stream_head_part(e));
-    HIPCHK(hipMemsetAsync(sa.pace, 0, stream_pace_part(), e->stream));
-    HIPCHK(hipMemsetAsync(sa.dp_head, 0xFF, stream_head_part(e), e->stream));  // DP_NONE
-    hipLaunchKernelGGL(g_stream_fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, sa);
+    sa.pace = w.pace;
+    sa.dp_head = w.dp_head;
+    sa.dp_link = w.dp_link;
+    HIPCHK(hipMemsetAsync(sa.pace, 0, stream_pace_part(), sA));
+    HIPCHK(hipMemsetAsync(sa.dp_head, 0xFF, stream_head_part(e), sA));  // DP_NONE
+    HIPCHK(hipEventRecord(e->ev_start[b], sA));
+    hipLaunchKernelGGL(g_stream_fn, dim3(e->grid), dim3(WALK_BLOCK), lds, sA, sa);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev_stop[b], sA));
+    // clock stamps written by workgroup 0 behind the pacing table (the next launch clears the table: copy on sA)
+    HIPCHK(hipMemcpyAsync(e->count_host + 2 + b * PACE_TAIL, w.pace + PACE_KEYS * 4, PACE_TAIL * sizeof(u32),
+                          hipMemcpyDeviceToHost, sA));
+    HIPCHK(hipEventRecord(e->ev_walk[b], sA));
+    HIPCHK(hipStreamWaitEvent(sB, e->ev_walk[b], 0));
     // distances: D += sum over the launch's jump-index history, and the distances of the launch's DP items
-    // (inside the timed region)
     const u32 sum_grid = (u32)((e->cap / 2 + WALK_BLOCK - 1) / WALK_BLOCK);  // one thread per pair of slots and lane
+    HIPCHK(hipEventRecord(e->ev_sum0[b], sB));
     if (e->DW == 3)
-      hipLaunchKernelGGL(kg_hist_sum_kernel<3>, dim3(sum_grid), dim3(WALK_BLOCK), 0, e->stream, sa.hist, e->jt, e->D,
+      hipLaunchKernelGGL(kg_hist_sum_kernel<3>, dim3(sum_grid), dim3(WALK_BLOCK), 0, sB, sa.hist, e->jt, e->D,
                          e->cap, e->n, e->threads, (u32)e->K, e->nb_run, sa.dp_head, sa.dp_link, e->out_dev[b]);
     else
-      hipLaunchKernelGGL(kg_hist_sum_kernel<8>, dim3(sum_grid), dim3(WALK_BLOCK), 0, e->stream, sa.hist, e->jt, e->D,
+      hipLaunchKernelGGL(kg_hist_sum_kernel<8>, dim3(sum_grid), dim3(WALK_BLOCK), 0, sB, sa.hist, e->jt, e->D,
                          e->cap, e->n, e->threads, (u32)e->K, e->nb_run, sa.dp_head, sa.dp_link, e->out_dev[b]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev_sum1[b], sB));
   } else {
-    hipLaunchKernelGGL(v->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, e->stream, a);
+    HIPCHK(hipEventRecord(e->ev_start[b], sA));
+    hipLaunchKernelGGL(v->fn, dim3(e->grid), dim3(WALK_BLOCK), lds, sA, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev_stop[b], sA));
   }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(e->ev_stop[b], e->stream));
-  HIPCHK(hipMemcpyAsync(e->count_host + b, e->count_dev + b, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-  if (pace)  // clock stamps written by workgroup 0 behind the pacing table
-    HIPCHK(hipMemcpyAsync(e->count_host + 2 + b * PACE_TAIL, pace + PACE_KEYS * 4, PACE_TAIL * sizeof(u32),
-                          hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(hipEventRecord(e->ev_done[b], e->stream));
-  e->inflight = b;
+  HIPCHK(hipMemcpyAsync(e->count_host + b, e->count_dev + b, sizeof(u32), hipMemcpyDeviceToHost, sB));
+  HIPCHK(hipEventRecord(e->ev_done[b], sB));
+  e->q[e->qn++] = b;
   e->next_buf = b ^ 1;
   return KG_OK;
 }
 
-extern "C" int kg_kick(kg_engine *e) {
-  const int rc = kick_checks(e);
+static int kick_depth(kg_engine *e, int depth) {
+  const int rc = kick_checks(e, depth);
   if (rc != KG_OK) return rc;
-  // the DP buffer this launch appends to follows the configuration (the other one may still hold the previous
-  // launch's items, which kg_launch unpacks after this call)
+  // the DP buffer this launch appends to follows the configuration (the other one may still hold a launch in flight
+  // or the previous launch's items, which kg_launch unpacks after this call)
   const int rr = ring_ensure(e, e->next_buf);
   if (rr != KG_OK) return rr;
   if (e->streaming) {
-    const size_t need = stream_ws_need(e);  // grows with nb_run (kg_set_nb_run) and the DP ring; kept between launches
+    const size_t need = stream_ws_need(e, 2);  // grows with nb_run (kg_set_nb_run) and the DP ring; kept between launches
     if (need > e->ws_bytes) {
-      HIPCHK(hipStreamSynchronize(e->stream));
+      if (sync_streams(e) != KG_OK) return KG_ERR_HIP;
       if (e->ws) (void)hipFree(e->ws);
       e->ws = nullptr;
       e->ws_bytes = 0;
       HIPCHK(hipMalloc((void **)&e->ws, need));
       e->ws_bytes = need;
+    } else if (need != e->ws_laid_out && e->qn > 0) {
+      // same allocation, other layout (nb_run or the ring changed while a launch is in flight): let it finish first
+      if (sync_streams(e) != KG_OK) return KG_ERR_HIP;
     }
+    e->ws_laid_out = need;
   }
-  return launch_walk(e, e->ws);
+  return launch_walk(e, e->ws, 2);
 }
+
+extern "C" int kg_kick(kg_engine *e) { return kick_depth(e, 0); }
 
 // kg_kick for callers that cannot allocate: the streaming kernel's workspace is the library's static device
 // array instead of a hipMalloc'd buffer.  No hipMalloc / hipFree / allocating routine on this path.
 extern "C" int kg_kick_static(kg_engine *e) {
-  const int rc = kick_checks(e);
+  const int rc = kick_checks(e, 0);
   if (rc != KG_OK) return rc;
   if (!e->streaming) return fail(KG_ERR_ARG, "kg_kick_static: the engine does not run the streaming kernel");
   if (e->ring_cap[e->next_buf] < ring_want(e))  // growing it would allocate: kg_set_params / kg_set_nb_run do that while idle
     return fail(KG_ERR_STATE, "kg_kick_static: the DP ring is smaller than this configuration needs; call kg_set_params / "
                               "kg_set_nb_run while no launch is in flight (they size it), or kg_kick once");
-  const size_t need = stream_ws_need(e);
+  const size_t need = stream_ws_need(e, 1);
   if (need > (size_t)KG_STATIC_WORKSPACE_BYTES) {
     char msg[200];
     snprintf(msg, sizeof msg, "kg_kick_static: this herd and step count need %zu bytes of workspace, the static workspace holds %zu",
@@ -844,16 +920,24 @@ extern "C" int kg_kick_static(kg_engine *e) {
   }
   void *ws = (e->gpu >= 0 && e->gpu < KG_MAX_DEVICES) ? g_scratch_ptr[e->gpu] : nullptr;  // looked up in kg_create
   if (!ws) return fail(KG_ERR_STATE, "kg_kick_static: static workspace address unknown for this device");
-  return launch_walk(e, ws);
+  return launch_walk(e, ws, 1);
 }
 
-static int wait_launch(kg_engine *e, int b) {
+// wait for the oldest launch in flight and take it off the queue; *buf = its launch buffer
+static int wait_oldest(kg_engine *e, int *buf) {
+  const int b = e->q[0];
   HIPCHK(hipEventSynchronize(e->ev_done[b]));
+  e->q[0] = e->q[1];
+  e->q[1] = -1;
+  --e->qn;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, e->ev_start[b], e->ev_stop[b]) == hipSuccess) e->last_ms = ms;
+  e->last_sum_ms = 0.f;
+  if (e->streaming && hipEventElapsedTime(&ms, e->ev_sum0[b], e->ev_sum1[b]) == hipSuccess) e->last_sum_ms = ms;
   const u32 *st = e->count_host + 2 + b * PACE_TAIL;
   e->last_clk = (u64)st[0] | ((u64)st[1] << 32);
   e->last_ref = (u64)st[2] | ((u64)st[3] << 32);
+  *buf = b;
   return KG_OK;
 }
 
@@ -888,10 +972,8 @@ extern "C" int kg_collect(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *
   if (lost) *lost = 0;
   int b = e->pending;
   if (b < 0) {
-    b = e->inflight;
-    if (b < 0) return fail(KG_ERR_STATE, "GPUEngine: Launch: no launch in flight");
-    if (bind(e) != KG_OK || wait_launch(e, b) != KG_OK) return KG_ERR_HIP;
-    e->inflight = -1;
+    if (e->qn == 0) return fail(KG_ERR_STATE, "GPUEngine: Launch: no launch in flight");
+    if (bind(e) != KG_OK || wait_oldest(e, &b) != KG_OK) return KG_ERR_HIP;
   }
   e->pending = -1;
   return unpack(e, b, items, cap, n, lost);
@@ -902,17 +984,29 @@ extern "C" int kg_launch(kg_engine *e, kg_item *items, uint32_t cap, uint32_t *n
   if (n) *n = 0;
   if (lost) *lost = 0;
   int b = e->pending;
-  if (b < 0) {
-    b = e->inflight;
-    if (b < 0) return fail(KG_ERR_STATE, "GPUEngine: Launch: no launch in flight");
-    if (bind(e) != KG_OK || wait_launch(e, b) != KG_OK) return KG_ERR_HIP;
-    e->inflight = -1;
+  int rk;
+  if (b >= 0) {  // completed by kg_kick_and_wait
+    e->pending = -1;
+    rk = kick_depth(e, 0);
+  } else {
+    if (e->qn == 0) return fail(KG_ERR_STATE, "GPUEngine: Launch: no launch in flight");
+    // Queue the next launch BEFORE waiting for the one in flight: the GPU goes from one walk kernel straight into the
+    // next, and the history kernel of the launch awaited here runs underneath it on the second stream.  The next
+    // launch uses the other launch buffer, whose items the previous call has already unpacked.
+    rk = e->qn == 1 ? kick_depth(e, 1) : KG_OK;
+    if (bind(e) != KG_OK || wait_oldest(e, &b) != KG_OK) return KG_ERR_HIP;
   }
-  e->pending = -1;
-  // queue the next launch first: the GPU walks while the host unpacks buffer b
-  const int rk = kg_kick(e);
   const int ru = unpack(e, b, items, cap, n, lost);
   return ru != KG_OK ? ru : rk;
+}
+
+extern "C" int kg_kick_and_wait(kg_engine *e) {
+  const int r = kg_kick(e);
+  if (r != KG_OK) return r;
+  int b = -1;
+  if (wait_oldest(e, &b) != KG_OK) return KG_ERR_HIP;
+  e->pending = b;
+  return KG_OK;
 }
 
 extern "C" int kg_dp_capacity(const kg_engine *e, uint32_t *items) {
@@ -921,13 +1015,9 @@ extern "C" int kg_dp_capacity(const kg_engine *e, uint32_t *items) {
   return KG_OK;
 }
 
-extern "C" int kg_kick_and_wait(kg_engine *e) {
-  const int r = kg_kick(e);
-  if (r != KG_OK) return r;
-  const int b = e->inflight;
-  if (wait_launch(e, b) != KG_OK) return KG_ERR_HIP;
-  e->inflight = -1;
-  e->pending = b;
+extern "C" int kg_last_sum_kernel_ms(const kg_engine *e, float *ms) {
+  if (!e || !ms) return fail(KG_ERR_ARG, "kg_last_sum_kernel_ms: bad argument");
+  *ms = e->last_sum_ms;
   return KG_OK;
 }
 

@@ -82,6 +82,7 @@ def load_library():
         "kg_kick_and_wait": ([H], C.c_int),
         "kg_dp_capacity": ([H, C.POINTER(C.c_uint32)], C.c_int),
         "kg_last_kernel_ms": ([H, C.POINTER(C.c_float)], C.c_int),
+        "kg_last_sum_kernel_ms": ([H, C.POINTER(C.c_float)], C.c_int),
         "kg_last_kernel_clock": ([H, _u64p, _u64p], C.c_int),
         "kg_kernel_info": ([H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "kg_kernel_name": ([H, C.c_char_p, C.c_size_t], C.c_int),
@@ -105,7 +106,7 @@ ABI_SYMBOLS = [
     "kg_device_count", "kg_default_grid", "kg_create", "kg_create_tuned", "kg_destroy", "kg_device_name", "kg_memory_bytes",
     "kg_nb_thread", "kg_group_size", "kg_nb_kangaroo", "kg_set_wild_offset", "kg_set_params", "kg_set_kangaroos",
     "kg_get_kangaroos", "kg_herd_from_distances", "kg_set_kangaroo", "kg_set_nb_run", "kg_kick", "kg_kick_static", "kg_collect", "kg_launch",
-    "kg_kick_and_wait", "kg_dp_capacity", "kg_last_kernel_ms", "kg_last_kernel_clock", "kg_kernel_info", "kg_kernel_name", "kg_field_kat", "kg_alloc_pinned", "kg_free_pinned",
+    "kg_kick_and_wait", "kg_dp_capacity", "kg_last_kernel_ms", "kg_last_sum_kernel_ms", "kg_last_kernel_clock", "kg_kernel_info", "kg_kernel_name", "kg_field_kat", "kg_alloc_pinned", "kg_free_pinned",
     "kg_print_device_info", "kg_device_pci_bus_id", "kg_last_error", "kg_version",
 ]
 
@@ -215,6 +216,12 @@ class GPUEngine:
     def LastKernelMs(self):
         ms = C.c_float(0)
         _chk(self._L.kg_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def LastSumKernelMs(self):
+        """Duration of the last completed launch's history kernel (kg_last_sum_kernel_ms)."""
+        ms = C.c_float(0)
+        _chk(self._L.kg_last_sum_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
     def LastKernelClockMHz(self):

@@ -193,7 +193,8 @@ def test_config5_default_grid_dp8_drain_without_loss():
     distinguished points per launch.  The caller's maxFound is the reference's 131 072 (core/kangaroo.cpp:408), with
     which the reference exits at the first launch (engine.cu:506-510); here the DP ring follows the DP mask
     (kg_dp_capacity).  Five launches: nothing lost, every item a DP, table + dead == DPs drained, and the kernel is not
-    slowed down by the reporting (round 2: -27 % at this DP size)."""
+    slowed down much by the reporting (round 2: -27 % at this DP size; now the walk kernel only chains the item to its
+    kangaroo and the distances are filled in by the history kernel on the second stream)."""
     gx, gy = GPUEngine.GetGridSize(0)
     lo, hi = 0, (1 << 110) - 1
     pub = host.ec_mul_g(0x2545F4914F6CDD1D0123456789ABCDEF % hi)
@@ -212,11 +213,12 @@ def test_config5_default_grid_dp8_drain_without_loss():
     eng.SetParams(solve.dp_mask_of(8), jd, jx, jy)
     assert eng.DpCapacity() >= 2 * n
     rng = host.Rng(18)
-    launches, n_dp, reseeded, ms = 5, 0, 0, []
+    launches, n_dp, reseeded, ms, ms_sum = 5, 0, 0, [], []
     eng.callKernel()
     for i in range(launches):
         items = eng.Launch(copy=False) if i < launches - 1 else eng.Collect(copy=False)
         ms.append(eng.LastKernelMs())
+        ms_sum.append(eng.LastSumKernelMs())
         assert eng.lost == 0
         assert not np.any(items["x"][:, 3] >> np.uint64(56))
         n_dp += len(items)
@@ -238,8 +240,9 @@ def test_config5_default_grid_dp8_drain_without_loss():
         if int(it["kIdx"]) & 1:
             pt = host.ec_add(pt, sv.key)
         assert pt[0] == host.to_int(it["x"])
-    print(f"DP=32 kernel {ms_quiet:.2f} ms, DP=8 kernel {sorted(ms)[len(ms) // 2]:.2f} ms (8.4 M DPs per launch)")
-    assert sorted(ms)[len(ms) // 2] < 1.25 * ms_quiet
+    print(f"walk kernel: DP=32 {ms_quiet:.2f} ms, DP=8 {sorted(ms)[len(ms) // 2]:.2f} ms (8.4 M DPs per launch); history kernel "
+          f"at DP=8 {sorted(ms_sum)[len(ms_sum) // 2]:.2f} ms, on the second stream underneath the next walk kernel")
+    assert sorted(ms)[len(ms) // 2] < 1.12 * ms_quiet
 
 
 @pytest.mark.timeout(700)
