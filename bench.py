@@ -383,7 +383,7 @@ def main():
                    "kangaroos_per_lane": info["k_per_lane"], "delta_words": info["delta_words"],
                    "lds_bytes_per_workgroup": info["lds_bytes"], "workgroups": info["grid"], "dps_seen": n_dp,
                    "self_check": {"invariant": "P_i == d_i*G (+ key for wild) after the timed launches",
-                                  "sampled_per_gpu": args.check, "bad": 0}},
+                                  "sampled_per_gpu": args.check, "ranks_checked": int(dist.sum_over_ranks(1)), "bad": 0}},
         "roofline": {"bound": "valu-int32-mul", "achieved": achieved / 1e12, "peak": PEAK_MAD32_PER_S / 1e12,
                      "unit": "TMAD32/s", "frac": achieved / PEAK_MAD32_PER_S, "traffic": traffic,
                      "traffic_source": "profiles/r03_pmc_hbm.json (rocprofv3 --pmc passes over this command, not measured in this run)"

@@ -64,8 +64,9 @@ int kg_create(int gpu_id, int groups, int per_group, uint32_t max_found, kg_engi
 /* kg_create with explicit kernel tuning (the reference's counterpart is the compile-time choice of
  * GPU_GRP_SIZE / -maxrregcount, constants.h:15 and Makefile:11-14; there is no runtime knob there).
  * tune == NULL is kg_create.  Used by the parity tests and the throughput sweep to pin a kernel form. */
-#define KG_MODE_AUTO 0   /* streaming kernel; register-resident one for herds beyond its 4 GiB workspace */
-#define KG_MODE_STREAM 1 /* streaming kernel or KG_ERR_ARG */
+#define KG_MODE_AUTO 0   /* streaming kernel; KG_ERR_ARG for herds beyond its 4 GiB workspace (44.7 M kangaroos per engine: \
+                            split larger herds over several engines, as `-gpuId 0,0` does, or ask for KG_MODE_REG) */
+#define KG_MODE_STREAM 1 /* the same, explicitly */
 #define KG_MODE_REG 2    /* register-resident kernel (herd in VGPRs for the whole launch) */
 typedef struct {
   int mode;       /* KG_MODE_* */

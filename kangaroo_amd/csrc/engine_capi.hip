@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kangaroo_amd.h"
@@ -92,7 +93,6 @@ struct kg_engine {
   u32 threads = 0, grid = 0;
   int K = 0, DW = 0;
   bool streaming = false;     // streaming kernel (walk_kernel_stream.h) instead of the register-resident one
-  bool fell_back = false;     // streaming was wanted but the herd is beyond its 4 GiB workspace limit
   u32 *ws = nullptr;          // its workspace
   size_t ws_bytes = 0;
   size_t ws_laid_out = 0;     // stream_ws_need the current layout of ws was computed for
@@ -430,23 +430,24 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
     u64 k = want_k > 0 ? (u64)want_k : std::max<u64>((e->n + lanes - 1) / lanes, 4);
     k = std::min<u64>(std::max<u64>(k, 2), 1024);
     k += k & 1;
-    // the streaming kernel addresses its workspace through ONE 32-bit buffer descriptor: with the padding this
-    // geometry implies it must stay below 4 GiB (about 39 M kangaroos); larger herds run on the register-resident
-    // kernel, 25 % slower, and kg_kernel_name says so
+    // The streaming kernel addresses its workspace through ONE 32-bit buffer descriptor: 96 bytes per kangaroo slot
+    // must stay below 4 GiB, i.e. at most 44.7 M kangaroos per engine (2^32 / 96; 4.3 GB of herd state).  A larger herd
+    // is REFUSED rather than silently moved to the register-resident kernel, which is 25 % slower and spills
+    // (profiles/r02_kernel_resources.txt): the caller splits it over several engines on the device, as the
+    // reference's `-gpuId 0,0` does (core/kangaroo.cpp:780-786; tests/test_gpu_configs.py runs two engines on one
+    // GPU), or asks for KG_MODE_REG explicitly.  The reference's own limit is its int offset, ~178 M (engine.cu:17).
     const u64 lanes_k = ((e->n + k - 1) / k + WALK_BLOCK - 1) / WALK_BLOCK * WALK_BLOCK;
     if (lanes_k * k * (u64)(WS_SLOT_WORDS * 4) >= (1ull << 32)) {
-      if (want_mode == KG_MODE_STREAM) {
-        delete e;
-        return fail(KG_ERR_ARG, "kg_create: herd too large for the streaming kernel's 4 GiB workspace");
-      }
-      e->streaming = false;
-      e->fell_back = true;
-    } else {
-      e->K = (int)k;
+      char msg[256];
+      snprintf(msg, sizeof msg, "kg_create: %llu kangaroos are beyond the streaming kernel's 4 GiB workspace (44.7 M per engine): "
+               "use several engines on the device or KG_MODE_REG", (unsigned long long)e->n);
+      delete e;
+      return fail(KG_ERR_ARG, msg);
     }
+    e->K = (int)k;
   }
   if (!e->streaming) {
-    e->K = (want_k > 0 && !e->fell_back) ? want_k : 16;
+    e->K = want_k > 0 ? want_k : 16;
     if (!find_variant(e->K, 3)) {
       delete e;
       return fail(KG_ERR_ARG, "kg_create: the register-resident kernel is built for 16 kangaroos per lane");
@@ -946,14 +947,27 @@ static int unpack(kg_engine *e, int b, kg_item *items, uint32_t cap, uint32_t *n
   const u32 stored = std::min(found, e->ring_cap[b]);
   const u32 take = std::min(stored, cap);
   const DpItemDev *src = e->out_host[b];
-  for (u32 i = 0; i < take; ++i) {
-    kg_item &it = items[i];
-    for (int k = 0; k < 4; ++k) {
-      it.x[k] = (u64)src[i].x[2 * k] | ((u64)src[i].x[2 * k + 1] << 32);
-      it.d[k] = (u64)src[i].d[2 * k] | ((u64)src[i].d[2 * k + 1] << 32);
+  auto convert = [&](u32 lo, u32 hi) {
+    for (u32 i = lo; i < hi; ++i) {
+      kg_item &it = items[i];
+      for (int k = 0; k < 4; ++k) {
+        it.x[k] = (u64)src[i].x[2 * k] | ((u64)src[i].x[2 * k + 1] << 32);
+        it.d[k] = (u64)src[i].d[2 * k] | ((u64)src[i].d[2 * k + 1] << 32);
+      }
+      it.kIdx = src[i].kidx;
+      if (it.kIdx & 1) order_sub(it.d, it.d, e->wild);  // engine.cu:534
     }
-    it.kIdx = src[i].kidx;
-    if (it.kIdx & 1) order_sub(it.d, it.d, e->wild);  // engine.cu:534
+  };
+  if (take < (1u << 18)) {
+    convert(0, take);
+  } else {
+    // low DP sizes: millions of items per launch (8.4 M at DP = 8 on the default grid), converted by a few threads
+    const u32 nt = std::min<u32>(8, std::max<u32>(1, std::thread::hardware_concurrency()));
+    const u32 per = (take + nt - 1) / nt;
+    std::vector<std::thread> th;
+    for (u32 t = 1; t < nt; ++t) th.emplace_back(convert, std::min(take, t * per), std::min(take, (t + 1) * per));
+    convert(0, std::min(take, per));
+    for (auto &t : th) t.join();
   }
   if (n) *n = take;
   const u32 dropped = found - take;
@@ -1043,8 +1057,7 @@ extern "C" int kg_kernel_name(const kg_engine *e, char *buf, size_t buflen) {
   }
   const Variant *v = find_variant(e->K, dw);
   if (!v) return fail(KG_ERR_STATE, "kg_kernel_name: no kernel variant for this configuration");
-  snprintf(buf, buflen, "kg_walk_kernel_rot<%d,%d,%d,%d>%s", v->K, v->U, v->DW, v->W,
-           e->fell_back ? " (fallback: herd beyond the streaming kernel's 4 GiB workspace)" : "");
+  snprintf(buf, buflen, "kg_walk_kernel_rot<%d,%d,%d,%d>", v->K, v->U, v->DW, v->W);
   return KG_OK;
 }
 
