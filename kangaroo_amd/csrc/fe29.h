@@ -93,6 +93,18 @@ KG_HD void fe_sub2_wide(fe &r, const fe &a, const fe &b, const fe &c) {
   for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + fe_b4(i) - b.l[i] - c.l[i];
 }
 
+// The same subtractions with the subtrahend already lifted and negated: c = 2p' - b (resp. 4p' - b) limb by limb,
+// prepared once for constants that are subtracted over and over (the jump table).  Results are WIDE, limb for limb
+// the values fe_sub_wide(r, a, b) and fe_sub2_wide(r, a, b, x) give.
+KG_HD void fe_add_lifted(fe &r, const fe &a, const fe &c) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + c.l[i];
+}
+KG_HD void fe_add_lifted_sub(fe &r, const fe &a, const fe &c4, const fe &x) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + c4.l[i] - x.l[i];
+}
+
 // ---- carry + fold bit 256 and above: wide -> weak ------------------------------------------
 KG_HD void fe_weak(fe &r) {
   u32 c = 0;

@@ -69,6 +69,15 @@ constexpr u32 PACE_TAIL = 4;
 #ifndef KG_WS_PAIRS
 #define KG_WS_PAIRS 1
 #endif
+// 1: the LDS copy of the jump table holds the subtrahends already lifted and negated — per row 2p' - jPx, 2p' - jPy and
+// 4p' - jPx (p' = the limb-lifted multiples of p that fe_sub_wide / fe_sub2_wide add, fe29.h) — so that
+// x - jPx, y - jPy and s^2 - jPx - x cost one limb-wise add (two for the last) instead of two (three): 36 VALU
+// instructions fewer per jump, and jPx is not held in registers between the dx and the rx of a jump.
+// 0: rows hold jPx, jPy as they are (round 1-2).
+#ifndef KG_JT_NEG
+#define KG_JT_NEG 1
+#endif
+constexpr int SJT_STRIDE = KG_JT_NEG ? 27 : JT_STRIDE;  // words of an LDS row (odd: spreads the banks)
 typedef __amdgpu_buffer_rsrc_t ws_rsrc;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 constexpr u32 WS_ROWS = 6;                  // rows of a slot: 0,1 = x, 2,3 = y, 4,5 = stored partial product
@@ -145,8 +154,8 @@ template <int W>
 __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArgs sa) {
   const WalkArgs &a = sa.a;
   extern __shared__ u32 lds[];
-  u32 *jt = lds;                           // [64][JT_STRIDE]
-  u32 *inv_ex = lds + NB_JUMP * JT_STRIDE;  // [8][9][64]: products in, inverses out (shared inversion)
+  u32 *jt = lds;                            // [64][SJT_STRIDE]
+  u32 *inv_ex = lds + NB_JUMP * SJT_STRIDE;  // [8][9][64]: products in, inverses out (shared inversion)
 
   const u32 tid = threadIdx.x;
   // clock stamps (workgroup 0 reports them at the end): the shader clock counter against the constant 100 MHz
@@ -154,7 +163,13 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   const u64 stamp_clk = __builtin_amdgcn_s_memtime(), stamp_ref = __builtin_amdgcn_s_memrealtime();
   for (u32 i = tid; i < NB_JUMP * 18; i += WALK_BLOCK) {
     u32 row = i / 18, col = i % 18;
-    jt[row * JT_STRIDE + col] = a.jt->pxy[row][col];
+    const u32 v = a.jt->pxy[row][col];
+#if KG_JT_NEG
+    jt[row * SJT_STRIDE + col] = fe_b2(col % 9) - v;              // 2p' - jPx | 2p' - jPy
+    if (col < 9) jt[row * SJT_STRIDE + 18 + col] = fe_b4(col) - v;  // 4p' - jPx
+#else
+    jt[row * SJT_STRIDE + col] = v;
+#endif
   }
   // physical CU of this workgroup: HW_ID (cu_id 11:8, sh_id 12, se_id 15:13) and XCC_ID; first come, first slot
   const u32 pace_key = ((__builtin_amdgcn_s_getreg(0xF804) >> 8) & 0xFFu) | ((__builtin_amdgcn_s_getreg(0x1814) & 0xFu) << 8);
@@ -185,11 +200,15 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     const pk256 xw = pk_from_planes(a.X, a.cap, p), yw = pk_from_planes(a.Y, a.cap, p);
     fe x;
     fe_unpack(x, xw);
-    const u32 *row = jt + (x.l[0] & (NB_JUMP - 1)) * JT_STRIDE;
+    const u32 *row = jt + (x.l[0] & (NB_JUMP - 1)) * SJT_STRIDE;
     fe jx, dx;
 #pragma unroll
     for (int i = 0; i < 9; ++i) jx.l[i] = row[i];
+#if KG_JT_NEG
+    fe_add_lifted(dx, x, jx);
+#else
     fe_sub_wide(dx, x, jx);
+#endif
     fe_mul(acc, dx, acc);
     ws_store<0>(wr, k, xw);
     ws_store<2>(wr, k, yw);
@@ -211,10 +230,22 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
 #pragma unroll
     for (int i = 0; i < 9; ++i) jy.l[i] = row[9 + i];
     fe dy, s, p2, rx, tt, ry;
+#if KG_JT_NEG
+    fe_add_lifted(dy, y, jy);
+    fe_mul(s, dy, dxi);
+    fe_sqr(p2, s);
+    {
+      fe c4;  // 4p' - jPx, fetched where it is needed: nothing of the jump point stays in registers across the multiplications
+#pragma unroll
+      for (int i = 0; i < 9; ++i) c4.l[i] = row[18 + i];
+      fe_add_lifted_sub(rx, p2, c4, x);
+    }
+#else
     fe_sub_wide(dy, y, jy);
     fe_mul(s, dy, dxi);
     fe_sqr(p2, s);
     fe_sub2_wide(rx, p2, jx, x);
+#endif
     fe_canon(rx);
     fe_sub_wide(tt, x, rx);
     fe_mul(ry, tt, s);
@@ -225,11 +256,15 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     fe_pack(xw, rx);
     fe_pack(yw, ry);
     {
-      const u32 *row2 = jt + (rx.l[0] & (NB_JUMP - 1)) * JT_STRIDE;
+      const u32 *row2 = jt + (rx.l[0] & (NB_JUMP - 1)) * SJT_STRIDE;
       fe jx2, dx2;
 #pragma unroll
       for (int i = 0; i < 9; ++i) jx2.l[i] = row2[i];
+#if KG_JT_NEG
+      fe_add_lifted(dx2, rx, jx2);
+#else
       fe_sub_wide(dx2, rx, jx2);
+#endif
       fe_mul(acc, dx2, acc);
     }
     ws_store<0>(wr, id, xw);
@@ -386,15 +421,20 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
 
       const u32 jmpA = xA.l[0] & (NB_JUMP - 1), jmpB = xB.l[0] & (NB_JUMP - 1);
       hist_run[(u64)(idB >> 1) * threads] = (unsigned short)(asc ? (jmpA | (jmpB << 8)) : (jmpB | (jmpA << 8)));
-      const u32 *rowA = jt + jmpA * JT_STRIDE, *rowB = jt + jmpB * JT_STRIDE;
+      const u32 *rowA = jt + jmpA * SJT_STRIDE, *rowB = jt + jmpB * SJT_STRIDE;
       fe jxA, jxB, dxA, dxB, dxiA, dxiB;
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         jxA.l[i] = rowA[i];
         jxB.l[i] = rowB[i];
       }
+#if KG_JT_NEG
+      fe_add_lifted(dxA, xA, jxA);
+      fe_add_lifted(dxB, xB, jxB);
+#else
       fe_sub_wide(dxA, xA, jxA);
       fe_sub_wide(dxB, xB, jxB);
+#endif
 #if KG_WS_PAIRS
       if (!last) {
         fe qA;
@@ -556,7 +596,7 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_hist_sum_kernel(const unsigned 
 }
 
 constexpr size_t walk_stream_lds_bytes() {
-  return (size_t)(NB_JUMP * JT_STRIDE + 8 * 9 * 64 + 4) * sizeof(u32);  // + the pacing slot
+  return (size_t)(NB_JUMP * SJT_STRIDE + 8 * 9 * 64 + 4) * sizeof(u32);  // + the pacing slot
 }
 
 }  // namespace kg

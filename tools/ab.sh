@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds on ONE box: for every ab/libkg_<name>.so given, the smoke parity check and a short bench.
+# A/B of library builds on ONE box: for every abv/libkg_<name>.so (tools/build_variant.sh) given, the smoke parity check and a short bench.
 # Usage (inside a gpurun call): bash tools/ab.sh <tag> <name> [<name> ...]      results: gpurun_out/ab_<tag>.txt
 set -o pipefail
 TAG=$1; shift
@@ -7,7 +7,7 @@ OUT=gpurun_out/ab_$TAG.txt
 mkdir -p gpurun_out; : > $OUT
 for round in 1 2; do
 for v in "$@"; do
-  export KANGAROO_AMD_LIB=$PWD/ab/libkg_$v.so
+  export KANGAROO_AMD_LIB=$PWD/abv/libkg_$v.so
   if [ $round -eq 1 ]; then
     timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" >> $OUT 2>&1 || { echo "$v: SMOKE FAILED" | tee -a $OUT; exit 1; }
   fi

@@ -94,6 +94,70 @@ KERNEL32(k_mad_u32_u24, L_MAD24)
 KERNEL32(k_mov_b32, L_MOV)
 KERNEL32(k_s_nop, L_NOP)
 
+// The rows above feed every instruction of a chain the SAME two multiplier operands (%8, %9): the multiplier array of a
+// lane sees no change from one instruction to the next, only the adder does.  The rows below give the eight
+// instructions of a block eight different operand pairs (random 32-bit values, random 52-bit mantissas), as a field
+// multiplication does, for the question "what does a 29 x 29-bit integer multiply-add cost against a double-precision
+// FMA that could carry a 52 x 52-bit product" (DESIGN.md section 3.1, FP64 multiplier).
+__global__ void __launch_bounds__(256, 2) k_mad_varied(u64 *out, u32 seed, u32 iters, u64 *clk) {
+  u64 c[8];
+  u32 x[8];
+  for (int i = 0; i < 8; ++i) {
+    c[i] = ((u64)(threadIdx.x * 2654435761u + seed + i) << 20) | 12345u;
+    x[i] = (threadIdx.x * 40503u + seed * 7919u + i * 0x9E3779B1u) * 2246822519u | 1u;
+  }
+  const u64 t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (u32 it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int rep = 0; rep < 16; ++rep)
+      asm volatile("v_mad_u64_u32 %0, s[40:41], %8, %9, %0\n\tv_mad_u64_u32 %1, s[40:41], %10, %11, %1\n\t"
+                   "v_mad_u64_u32 %2, s[40:41], %12, %13, %2\n\tv_mad_u64_u32 %3, s[40:41], %14, %15, %3\n\t"
+                   "v_mad_u64_u32 %4, s[40:41], %9, %12, %4\n\tv_mad_u64_u32 %5, s[40:41], %11, %14, %5\n\t"
+                   "v_mad_u64_u32 %6, s[40:41], %13, %8, %6\n\tv_mad_u64_u32 %7, s[40:41], %15, %10, %7\n\t"
+                   : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])
+                   : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7])
+                   : "s40", "s41", "vcc");
+  }
+  const u64 t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  u64 xo = 0;
+  for (int i = 0; i < 8; ++i) xo ^= c[i];
+  out[blockIdx.x * 256 + threadIdx.x] = xo;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+// doubles with random 52-bit mantissas in [2^51, 2^52): products near 2^103, accumulators start at 2^104 (the
+// alignment constant of the hi/lo product trick) and stay finite for the length of the run
+#define KERNEL_F64(NAME, I0, I1, I2, I3, I4, I5, I6, I7)                                                       \
+  __global__ void __launch_bounds__(256, 2) NAME(u64 *out, u32 seed, u32 iters, u64 *clk) {                    \
+    double c[8], x[8];                                                                                         \
+    for (int i = 0; i < 8; ++i) {                                                                              \
+      const u64 m = ((u64)((threadIdx.x * 40503u + seed * 7919u + i * 0x9E3779B1u) * 2246822519u) << 20) ^     \
+                    ((u64)(threadIdx.x * 2654435761u + i) * 0x2545F4914F6CDD1Dull >> 12);                       \
+      x[i] = (double)((m & ((1ull << 51) - 1)) | (1ull << 51));                                                \
+      c[i] = 20282409603651670423947251286016.0 + (double)i; /* 2^104 */                                       \
+    }                                                                                                          \
+    const u64 t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();                        \
+    for (u32 it = 0; it < iters; ++it) {                                                                       \
+      _Pragma("unroll") for (int rep = 0; rep < 16; ++rep)                                                     \
+        asm volatile(I0 I1 I2 I3 I4 I5 I6 I7                                                                   \
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]) \
+                     : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));  \
+    }                                                                                                          \
+    const u64 t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();                        \
+    double xo = 0;                                                                                             \
+    for (int i = 0; i < 8; ++i) xo += c[i];                                                                    \
+    out[blockIdx.x * 256 + threadIdx.x] = (u64)__double_as_longlong(xo);                                       \
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }                           \
+  }
+KERNEL_F64(k_fma_f64, "v_fma_f64 %0, %8, %9, %0\n\t", "v_fma_f64 %1, %10, %11, %1\n\t", "v_fma_f64 %2, %12, %13, %2\n\t",
+           "v_fma_f64 %3, %14, %15, %3\n\t", "v_fma_f64 %4, %9, %12, %4\n\t", "v_fma_f64 %5, %11, %14, %5\n\t",
+           "v_fma_f64 %6, %13, %8, %6\n\t", "v_fma_f64 %7, %15, %10, %7\n\t")
+KERNEL_F64(k_add_f64, "v_add_f64 %0, %0, %8\n\t", "v_add_f64 %1, %1, %9\n\t", "v_add_f64 %2, %2, %10\n\t",
+           "v_add_f64 %3, %3, %11\n\t", "v_add_f64 %4, %4, %12\n\t", "v_add_f64 %5, %5, %13\n\t",
+           "v_add_f64 %6, %6, %14\n\t", "v_add_f64 %7, %7, %15\n\t")
+KERNEL_F64(k_mul_f64, "v_mul_f64 %0, %8, %9\n\t", "v_mul_f64 %1, %10, %11\n\t", "v_mul_f64 %2, %12, %13\n\t",
+           "v_mul_f64 %3, %14, %15\n\t", "v_mul_f64 %4, %9, %12\n\t", "v_mul_f64 %5, %11, %14\n\t",
+           "v_mul_f64 %6, %13, %8\n\t", "v_mul_f64 %7, %15, %10\n\t")
+
 // mixed: the ratio of the walk kernel's hot loop (1 multiply-add : 1 simple op), interleaved
 #define L_MIX(i) "v_mad_u64_u32 %" #i ", s[40:41], %8, %9, %" #i "\n\tv_and_b32 %8, %8, %9\n\t"
 __global__ void __launch_bounds__(256, 2) k_mix(u64 *out, u32 seed, u32 iters, u64 *clk) {
@@ -203,6 +267,8 @@ int main(int argc, char **argv) {
       {"v_lshrrev_b64", k_lshrrev_b64, 128}, {"v_lshl_add_u64", k_lshl_add_u64, 128}, {"v_alignbit_b32", k_alignbit_b32, 128},
       {"v_add3_u32", k_add3_u32, 128}, {"v_mul_lo_u32", k_mul_lo_u32, 128}, {"v_mul_hi_u32", k_mul_hi_u32, 128},
       {"v_mad_u32_u24", k_mad_u32_u24, 128}, {"s_nop 0", k_s_nop, 128}, {"mad64 + and (1:1)", k_mix, 128},
+      {"mad_u64_u32 varied", k_mad_varied, 128}, {"v_fma_f64 varied", k_fma_f64, 128}, {"v_mul_f64 varied", k_mul_f64, 128},
+      {"v_add_f64 varied", k_add_f64, 128},
   };
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
@@ -228,10 +294,11 @@ int main(int argc, char **argv) {
     CHECK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
     const double mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0;
     const double instr_per_wave = (double)iters * r.per_iter;
-    // per SIMD: 2 waves issue instr_per_wave each
-    const double cyc = (double)h[0] / (2.0 * instr_per_wave);
     const double total = instr_per_wave * blocks * 4;  // wave-instructions
     const double rate = total / (ms * 1e-3);
+    // issue cycles per wave-instruction and SIMD, derived from the whole machine's rate (round 2 timed workgroup 0
+    // alone, which the arbiter favours: 2.61 "cycles" beside a rate that means 4.51)
+    const double cyc = mhz * 1e6 * (double)cus * 4.0 / rate;
     printf("%-18s %9.0f %9.0f %12.2f %14.1f %9.2f %12.2f\n", r.name, mhz, watts, cyc, rate / 1e9, ms * 1e-3,
            (watts - idle) / rate * 1e9);
     fflush(stdout);
