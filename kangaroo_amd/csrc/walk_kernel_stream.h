@@ -78,6 +78,27 @@ constexpr u32 PACE_TAIL = 4;
 #define KG_JT_NEG 1
 #endif
 constexpr int SJT_STRIDE = KG_JT_NEG ? 27 : JT_STRIDE;  // words of an LDS row (odd: spreads the banks)
+// MEASUREMENT VARIANT, off in the library (profiles/r03_levers.txt): 1 = ONE inversion per workgroup and step, computed
+// on ONE lane.  The inverting wave first folds the 64 per-lane products of the workgroup into one with a product tree
+// across its lanes (through LDS, KG_INV_TREE_LEVELS levels), inverts on the surviving lanes with every other lane
+// switched off, and walks the tree back down (Montgomery's trick across lanes): 18 multiplications with 63 + 126
+// active lanes in all, and an inversion that toggles one lane instead of 64.  Measured on MI355X: the shader clock
+// rises 3 % (less energy per cycle, the kernel runs at the board's power cap) but the launch takes 1.7 % LONGER (6
+// levels; 3 levels -0.9 %, 2 levels -0.4 %): the extra multiplications sit on the step's critical path, and cycles in
+// which the SIMDs wait still pay for clocks and leakage.
+// 0: the inverting wave inverts 64 values, one per lane (what ships).
+#ifndef KG_INV_TREE
+#define KG_INV_TREE 0
+#endif
+#ifndef KG_INV_TREE_LEVELS
+#define KG_INV_TREE_LEVELS 6  // 6: down to one lane; 3: down to eight lanes (half the multiplications on the critical path)
+#endif
+constexpr u32 INV_TREE_WORDS = KG_INV_TREE ? KG_INV_TREE_LEVELS * 9 * 64 : 0;
+// form of the single-lane inversion (modinv30.h): 2 = batches of branch-free iterations (what 64 lanes want),
+// 1 = a per-lane loop with data-dependent branches (one lane has nobody to diverge from)
+#ifndef KG_INV_TREE_MODE
+#define KG_INV_TREE_MODE 2
+#endif
 typedef __amdgpu_buffer_rsrc_t ws_rsrc;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 constexpr u32 WS_ROWS = 6;                  // rows of a slot: 0,1 = x, 2,3 = y, 4,5 = stored partial product
@@ -364,7 +385,57 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
         fe_mul(p01, a0, a1);
         fe_mul(p23, a2, a3);
         fe_mul(t, p01, p23);
+#if KG_INV_TREE
+        {
+          // Product tree over the lanes of this wave.  Level j pairs lane l (l a multiple of 2^(j+1)) with lane
+          // l + 2^j; tree[j] keeps what every lane held when the level started.  Only this wave is here (the other
+          // three wait at the barrier below), its LDS operations execute in program order, and the accesses are
+          // volatile so that the compiler keeps that order: no further synchronisation is needed inside a wave.
+          volatile u32 *tree = inv_ex + 8 * 9 * 64 + 4;  // [6][9][64]
+          fe cur = t;
+#pragma unroll 1
+          for (u32 j = 0; j < KG_INV_TREE_LEVELS; ++j) {
+            volatile u32 *lvl = tree + j * (9 * 64);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) lvl[i * 64 + lane] = cur.l[i];
+            __builtin_amdgcn_wave_barrier();
+            if ((lane & ((2u << j) - 1u)) == 0u) {
+              fe o;
+#pragma unroll
+              for (int i = 0; i < 9; ++i) o.l[i] = lvl[i * 64 + lane + (1u << j)];
+              fe_mul(cur, cur, o);
+            }
+          }
+          if ((lane & ((1u << KG_INV_TREE_LEVELS) - 1u)) == 0u) fe_inv_t<KG_INV_TREE_MODE>(iv, cur);  // every other lane is off: the 12 000 instructions of the inversion toggle one lane
+#pragma unroll 1
+          for (int j = KG_INV_TREE_LEVELS - 1; j >= 0; --j) {
+            volatile u32 *lvl = tree + (u32)j * (9 * 64);
+            const u32 span = 2u << j, half = 1u << j;
+            if ((lane & (span - 1u)) == 0u) {
+              // iv = (mine * theirs)^-1 as the level held them: theirs^-1 = iv * mine goes to the partner, mine^-1 = iv * theirs stays
+              fe mine, theirs, r2;
+#pragma unroll
+              for (int i = 0; i < 9; ++i) {
+                mine.l[i] = lvl[i * 64 + lane];
+                theirs.l[i] = lvl[i * 64 + lane + half];
+              }
+              fe_mul(r2, iv, mine);
+#pragma unroll
+              for (int i = 0; i < 9; ++i) lvl[i * 64 + lane + half] = r2.l[i];
+              fe_mul(iv, iv, theirs);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((lane & (span - 1u)) == half) {
+#pragma unroll
+              for (int i = 0; i < 9; ++i) iv.l[i] = lvl[i * 64 + lane];
+            }
+          }
+        }
+#elif defined(KG_TIMING_NO_INVERSION)
+        iv = t;  // TIMING EXPERIMENT ONLY (wrong results): what the inversion's place on the critical path costs
+#else
         fe_inv(iv, t);
+#endif
         fe_mul(i01, iv, p23);
         fe_mul(i23, iv, p01);
         fe_mul(r, i01, a1);
@@ -596,7 +667,7 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_hist_sum_kernel(const unsigned 
 }
 
 constexpr size_t walk_stream_lds_bytes() {
-  return (size_t)(NB_JUMP * SJT_STRIDE + 8 * 9 * 64 + 4) * sizeof(u32);  // + the pacing slot
+  return (size_t)(NB_JUMP * SJT_STRIDE + 8 * 9 * 64 + 4 + INV_TREE_WORDS) * sizeof(u32);  // + the pacing slot, + the lane tree
 }
 
 }  // namespace kg

@@ -38,6 +38,31 @@ def test_checker_flags_hand_made_violations():
     assert got == [("kern_bad", 2, 4), ("kern_ok", 0, 2)]
 
 
+BRANCHY = """
+0000000000003000 <kern_branch>:
+	buffer_store_dwordx4 v[10:13], v2, s[8:11], s20 offen      // 000000003000: E07C1000
+	s_nop 0                                                    // 000000003008: BF800000
+	s_cbranch_vccnz 3                                          // 00000000300C: BF870003 <kern_branch+0x1c>
+	s_nop 3                                                    // 000000003010: BF800003
+	v_add_u32_e32 v12, v1, v2                                  // 000000003014: 68180501
+	s_endpgm                                                   // 000000003018: BF810000
+	v_mov_b32_e32 v11, v6                                      // 00000000301C: 7E160306
+	s_endpgm                                                   // 000000003020: BF810000
+0000000000004000 <kern_indirect>:
+	buffer_store_dwordx4 v[10:13], v2, s[8:11], s20 offen      // 000000004000: E07C1000
+	s_setpc_b64 s[30:31]                                       // 000000004008: BE801D1E
+"""
+
+
+def test_checker_follows_branches_inside_the_window():
+    v, n_wide, _ = H.check(H.parse(BRANCHY))
+    assert n_wide == 2
+    got = sorted((name, ws, need) for name, _, _, ws, need in v)
+    # the fall-through side is padded (s_nop 3); the branch target overwrites v11 after 2 wait states; an indirect jump
+    # inside the window cannot be followed and is reported
+    assert got == [("kern_branch", 2, 4), ("kern_indirect", 0, 4)]
+
+
 def test_built_library_has_no_store_hazard():
     lib = os.path.join(ROOT, "kangaroo_amd", "libkangaroo_amd.so")
     assert os.path.exists(lib), "build the library first (__graft_entry__.build)"
