@@ -45,8 +45,8 @@ for i in range(launches):
         k_idx = int(items[di]["kIdx"])
         nx, ny, nd = host.create_herd(rng, sv.range_power, sv.range_width, sv.key, 1, k_idx % 2)
         eng.SetKangaroo(k_idx, nx[0], ny[0], nd[0])
+dt = time.perf_counter() - t0  # `launches` launches were awaited and ingested in the loop; the one still in flight is not timed
 eng.Collect()
-dt = time.perf_counter() - t0
 print(f"{eng.deviceName} {eng.KernelName()} kangaroos={n} dp_bits={dp_bits} launches={launches}")
 print(f"jumps/s (wall, host ingest in the loop) : {n * 256 * launches / dt / 1e9:.2f} G")
 print(f"walk kernel ms per launch               : median {sorted(kernel_ms)[len(kernel_ms) // 2]:.2f}, min {min(kernel_ms):.2f}, max {max(kernel_ms):.2f}")
