@@ -801,13 +801,9 @@ static bool check_key(kgh_solver *s, U256 d1, U256 d2, int t) {
 
 // One DP into its shard.  Returns 1 = stored, 0 = duplicate / same herd (dead kangaroo), 3 = tame/wild
 // collision (the caller resolves it with resolve_collision: EC work stays outside the shard lock).
-static int shard_add(kgh_solver *s, const U256 &x, const U256 &d, u64 k_idx, U256 *other_d, uint32_t *other_type) {
-  const uint32_t type = (uint32_t)(k_idx & 1);
-  Key128 key;
-  Entry e;
-  ht_convert(x, d, type, key, e);
-  Shard &sh = s->shard[shard_of(key)];
-  std::lock_guard<std::mutex> lock(sh.mu);
+// the shard's mutex is held by the caller; key / e as HashTable::Convert builds them
+static int shard_insert_locked(kgh_solver *s, Shard &sh, const Key128 &key, const Entry &e, uint32_t type, U256 *other_d,
+                               uint32_t *other_type) {
   bool existed;
   Entry *cell = sh.find_or_insert(key, e, &existed);
   if (!existed) return 1;
@@ -826,6 +822,15 @@ static int shard_add(kgh_solver *s, const U256 &x, const U256 &d, u64 k_idx, U25
   *other_d = d0;
   *other_type = t0;
   return 3;
+}
+static int shard_add(kgh_solver *s, const U256 &x, const U256 &d, u64 k_idx, U256 *other_d, uint32_t *other_type) {
+  const uint32_t type = (uint32_t)(k_idx & 1);
+  Key128 key;
+  Entry e;
+  ht_convert(x, d, type, key, e);
+  Shard &sh = s->shard[shard_of(key)];
+  std::lock_guard<std::mutex> lock(sh.mu);
+  return shard_insert_locked(s, sh, key, e, type, other_d, other_type);
 }
 // CollisionCheck (core/kangaroo.cpp:183-256): returns 2 = key found, 0 = wrong collision (dead kangaroo)
 static int resolve_collision(kgh_solver *s, const U256 &d, const U256 &d0, uint32_t t0) {
@@ -949,13 +954,32 @@ int kgh_solver_add_items(kgh_solver *s, const void *items, uint32_t n, uint32_t 
   std::vector<std::vector<uint32_t>> sdead(NSHARD);
   std::vector<std::vector<Coll>> scoll(NSHARD);
   s->pool.parallel_for(NSHARD, [&](int sh) {
-    for (uint32_t q = start[sh]; q < start[sh + 1]; ++q) {
-      const uint32_t i = order[q];
-      U256 d0;
-      uint32_t t0;
-      const int r = shard_add(s, load(it[i].x), load(it[i].d), it[i].kIdx, &d0, &t0);
-      if (r == 0) sdead[sh].push_back(i);
-      else if (r == 3) scoll[sh].push_back(Coll{i, d0, t0});
+    // The shard's items go in runs of up to RUN under ONE hold of the shard's mutex: first the home slots of the whole
+    // run are prefetched (the table is far larger than the caches: every insert is a miss otherwise), then the run is
+    // inserted in arrival order.  A grow() inside a run only makes the remaining prefetches useless.
+    constexpr uint32_t RUN = 32;
+    Shard &shard = s->shard[sh];
+    for (uint32_t q0 = start[sh]; q0 < start[sh + 1]; q0 += RUN) {
+      const uint32_t q1 = std::min<uint32_t>(q0 + RUN, start[sh + 1]);
+      Key128 keys[RUN];
+      Entry ents[RUN];
+      for (uint32_t q = q0; q < q1; ++q) {
+        const uint32_t i = order[q];
+        ht_convert(load(it[i].x), load(it[i].d), (uint32_t)(it[i].kIdx & 1), keys[q - q0], ents[q - q0]);
+      }
+      std::lock_guard<std::mutex> lock(shard.mu);
+      if (!shard.cells.empty()) {
+        const size_t mask = shard.cells.size() - 1;
+        for (uint32_t q = q0; q < q1; ++q) __builtin_prefetch(&shard.cells[Key128Hash()(keys[q - q0]) & mask], 1, 0);
+      }
+      for (uint32_t q = q0; q < q1; ++q) {
+        const uint32_t i = order[q];
+        U256 d0;
+        uint32_t t0;
+        const int r = shard_insert_locked(s, shard, keys[q - q0], ents[q - q0], (uint32_t)(it[i].kIdx & 1), &d0, &t0);
+        if (r == 0) sdead[sh].push_back(i);
+        else if (r == 3) scoll[sh].push_back(Coll{i, d0, t0});
+      }
     }
   });
   // 3. collisions between herds, in arrival order (EC arithmetic, rare)

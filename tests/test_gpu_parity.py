@@ -283,3 +283,32 @@ def test_nb_run_growth_and_arbitrary_dp_mask():
     gx, gy, gd = e.GetKangaroos()
     assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
     e.close()
+
+
+def test_dp_mask_lowered_while_a_launch_is_in_flight_grows_the_ring():
+    """SetParams with a much lower DP size while a launch is in flight: the launch under way keeps the old mask, the DP
+    ring of the launch queued next is grown at that kick (the other buffer still holds the launch in flight), nothing is
+    lost and every launch equals the oracle's walk with the mask that was current when it was queued."""
+    case = make_case(64, 128 * 4 * 64, seed=515, dp_bits=12)
+    hi_mask = case["dp_mask"]
+    lo_mask = 0xC000000000000000  # DP size 2: 8192 * ... a quarter of all points
+    e = _engine(4, 64, case, nb_run=24, mode="stream")
+    n = 128 * 4 * 64
+    cap0 = e.DpCapacity()
+    px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
+    e.callKernel()                      # launch 1, old mask
+    r1 = e.Launch()                     # launch 2 queued (old mask), launch 1 returned
+    assert dp_multiset(r1) == oracle_dps(case, px, py, d, 24)
+    e.SetParams(lo_mask, case["jd"], case["jx"], case["jy"])  # waits for launch 2, then the mask changes
+    assert e.DpCapacity() >= 2 * n * 24 // 4 > cap0
+    r2 = e.Launch()                     # launch 3 queued with the new mask into a ring grown now; launch 2 returned
+    assert dp_multiset(r2) == oracle_dps(case, px, py, d, 24)
+    case["dp_mask"] = lo_mask
+    r3 = e.Launch()
+    assert e.lost == 0 and abs(len(r3) - n * 24 / 4) < 6 * (n * 24 / 4) ** 0.5
+    assert dp_multiset(r3) == oracle_dps(case, px, py, d, 24)
+    r4 = e.Collect()
+    assert e.lost == 0 and dp_multiset(r4) == oracle_dps(case, px, py, d, 24)
+    gx, gy, gd = e.GetKangaroos()
+    assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
+    e.close()

@@ -99,31 +99,44 @@ KERNEL32(k_s_nop, L_NOP)
 // instructions of a block eight different operand pairs (random 32-bit values, random 52-bit mantissas), as a field
 // multiplication does, for the question "what does a 29 x 29-bit integer multiply-add cost against a double-precision
 // FMA that could carry a 52 x 52-bit product" (DESIGN.md section 3.1, FP64 multiplier).
-__global__ void __launch_bounds__(256, 2) k_mad_varied(u64 *out, u32 seed, u32 iters, u64 *clk) {
-  u64 c[8];
-  u32 x[8];
-  for (int i = 0; i < 8; ++i) {
-    c[i] = ((u64)(threadIdx.x * 2654435761u + seed + i) << 20) | 12345u;
-    x[i] = (threadIdx.x * 40503u + seed * 7919u + i * 0x9E3779B1u) * 2246822519u | 1u;
+#define MADV(c, x, y) "v_mad_u64_u32 %" #c ", s[40:41], %" #x ", %" #y ", %" #c "\n\t"
+#define KERNEL_MADV(NAME, I0, I1, I2, I3, I4, I5, I6, I7)                                                      \
+  __global__ void __launch_bounds__(256, 2) NAME(u64 *out, u32 seed, u32 iters, u64 *clk) {                    \
+    u64 c[8];                                                                                                  \
+    u32 x[8];                                                                                                  \
+    for (int i = 0; i < 8; ++i) {                                                                              \
+      c[i] = ((u64)(threadIdx.x * 2654435761u + seed + i) << 20) | 12345u;                                     \
+      x[i] = (threadIdx.x * 40503u + seed * 7919u + i * 0x9E3779B1u) * 2246822519u | 1u;                       \
+    }                                                                                                          \
+    const u64 t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();                        \
+    for (u32 it = 0; it < iters; ++it) {                                                                       \
+      _Pragma("unroll") for (int rep = 0; rep < 16; ++rep)                                                     \
+        asm volatile(I0 I1 I2 I3 I4 I5 I6 I7                                                                   \
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]) \
+                     : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7])  \
+                     : "s40", "s41", "vcc");                                                                   \
+    }                                                                                                          \
+    const u64 t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();                        \
+    u64 xo = 0;                                                                                                \
+    for (int i = 0; i < 8; ++i) xo ^= c[i];                                                                    \
+    out[blockIdx.x * 256 + threadIdx.x] = xo;                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }                           \
   }
-  const u64 t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  for (u32 it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int rep = 0; rep < 16; ++rep)
-      asm volatile("v_mad_u64_u32 %0, s[40:41], %8, %9, %0\n\tv_mad_u64_u32 %1, s[40:41], %10, %11, %1\n\t"
-                   "v_mad_u64_u32 %2, s[40:41], %12, %13, %2\n\tv_mad_u64_u32 %3, s[40:41], %14, %15, %3\n\t"
-                   "v_mad_u64_u32 %4, s[40:41], %9, %12, %4\n\tv_mad_u64_u32 %5, s[40:41], %11, %14, %5\n\t"
-                   "v_mad_u64_u32 %6, s[40:41], %13, %8, %6\n\tv_mad_u64_u32 %7, s[40:41], %15, %10, %7\n\t"
-                   : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])
-                   : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7])
-                   : "s40", "s41", "vcc");
-  }
-  const u64 t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  u64 xo = 0;
-  for (int i = 0; i < 8; ++i) xo ^= c[i];
-  out[blockIdx.x * 256 + threadIdx.x] = xo;
-  if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
-}
+// both operands change from one instruction to the next (a column of a field multiplication)
+KERNEL_MADV(k_mad_varied, MADV(0, 8, 9), MADV(1, 10, 11), MADV(2, 12, 13), MADV(3, 14, 15), MADV(4, 9, 12), MADV(5, 11, 14),
+            MADV(6, 13, 8), MADV(7, 15, 10))
+// neighbours share one operand, alternately the first and the second (a zig-zag through two columns at once)
+KERNEL_MADV(k_mad_zigzag, MADV(0, 8, 9), MADV(1, 8, 10), MADV(2, 11, 10), MADV(3, 11, 12), MADV(4, 13, 12), MADV(5, 13, 14),
+            MADV(6, 15, 14), MADV(7, 15, 9))
+// the first operand stays, the second changes (a row of the product: operand scanning)
+KERNEL_MADV(k_mad_fix0, MADV(0, 8, 9), MADV(1, 8, 10), MADV(2, 8, 11), MADV(3, 8, 12), MADV(4, 8, 13), MADV(5, 8, 14),
+            MADV(6, 8, 15), MADV(7, 8, 9))
+// the second operand stays, the first changes
+KERNEL_MADV(k_mad_fix1, MADV(0, 9, 8), MADV(1, 10, 8), MADV(2, 11, 8), MADV(3, 12, 8), MADV(4, 13, 8), MADV(5, 14, 8),
+            MADV(6, 15, 8), MADV(7, 9, 8))
+// both operands change, ONE accumulator chain (what a column really is: eight dependent multiply-adds)
+KERNEL_MADV(k_mad_chain, MADV(0, 8, 9), MADV(0, 10, 11), MADV(0, 12, 13), MADV(0, 14, 15), MADV(0, 9, 12), MADV(0, 11, 14),
+            MADV(0, 13, 8), MADV(0, 15, 10))
 // doubles with random 52-bit mantissas in [2^51, 2^52): products near 2^103, accumulators start at 2^104 (the
 // alignment constant of the hi/lo product trick) and stay finite for the length of the run
 #define KERNEL_F64(NAME, I0, I1, I2, I3, I4, I5, I6, I7)                                                       \
@@ -267,7 +280,8 @@ int main(int argc, char **argv) {
       {"v_lshrrev_b64", k_lshrrev_b64, 128}, {"v_lshl_add_u64", k_lshl_add_u64, 128}, {"v_alignbit_b32", k_alignbit_b32, 128},
       {"v_add3_u32", k_add3_u32, 128}, {"v_mul_lo_u32", k_mul_lo_u32, 128}, {"v_mul_hi_u32", k_mul_hi_u32, 128},
       {"v_mad_u32_u24", k_mad_u32_u24, 128}, {"s_nop 0", k_s_nop, 128}, {"mad64 + and (1:1)", k_mix, 128},
-      {"mad_u64_u32 varied", k_mad_varied, 128}, {"v_fma_f64 varied", k_fma_f64, 128}, {"v_mul_f64 varied", k_mul_f64, 128},
+      {"mad_u64_u32 varied", k_mad_varied, 128}, {"mad zig-zag operands", k_mad_zigzag, 128}, {"mad 1st operand fixed", k_mad_fix0, 128},
+      {"mad 2nd operand fixed", k_mad_fix1, 128}, {"mad varied, 1 chain", k_mad_chain, 128}, {"v_fma_f64 varied", k_fma_f64, 128}, {"v_mul_f64 varied", k_mul_f64, 128},
       {"v_add_f64 varied", k_add_f64, 128},
   };
   hipEvent_t e0, e1;
