@@ -64,8 +64,7 @@ int kg_create(int gpu_id, int groups, int per_group, uint32_t max_found, kg_engi
 /* kg_create with explicit kernel tuning (the reference's counterpart is the compile-time choice of
  * GPU_GRP_SIZE / -maxrregcount, constants.h:15 and Makefile:11-14; there is no runtime knob there).
  * tune == NULL is kg_create.  Used by the parity tests and the throughput sweep to pin a kernel form. */
-#define KG_MODE_AUTO 0   /* streaming kernel; KG_ERR_ARG for herds beyond its 4 GiB workspace (44.7 M kangaroos per engine: \
-                            split larger herds over several engines, as `-gpuId 0,0` does, or ask for KG_MODE_REG) */
+#define KG_MODE_AUTO 0   /* streaming kernel (herds beyond 44.7 M kangaroos, its 4 GiB workspace, run as several launch segments) */
 #define KG_MODE_STREAM 1 /* the same, explicitly */
 #define KG_MODE_REG 2    /* register-resident kernel (herd in VGPRs for the whole launch) */
 typedef struct {
@@ -73,6 +72,9 @@ typedef struct {
   int k_per_lane; /* kangaroos per lane; 0 = engine's choice.  Streaming: even, 2..1024; register-resident: 16 */
   uint32_t ring_max_items; /* upper bound of the DP ring per launch in items (80 bytes of pinned host memory each, two
                               buffers); 0 = the default, 2^25.  Never below the caller's max_found. */
+  uint64_t ws_limit_bytes; /* streaming kernel: most workspace bytes (96 per kangaroo) one kernel launch may address; 0 = the
+                              hardware's 4 GiB (one buffer descriptor).  A herd that needs more is walked in several launch
+                              segments per Launch.  Tests set it low to run segments on small herds. */
 } kg_tuning;
 int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t max_found, const kg_tuning *tune, kg_engine **out);
 /* Replaces GPUEngine::~GPUEngine (math/gpu/engine.cu:172-181). */

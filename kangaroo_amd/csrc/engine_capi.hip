@@ -91,7 +91,8 @@ struct kg_engine {
   int gpu = 0, groups = 0, per_group = 0;
   u64 n = 0, cap = 0;
   u32 threads = 0, grid = 0;
-  int K = 0, DW = 0;
+  int K = 0, DW = 0;          // kangaroos per lane (all launch segments together), distance-sum words
+  int nseg = 1, K_seg = 0;    // streaming kernel: the herd is walked in nseg launch segments of K_seg kangaroos per lane
   bool streaming = false;     // streaming kernel (walk_kernel_stream.h) instead of the register-resident one
   u32 *ws = nullptr;          // its workspace
   size_t ws_bytes = 0;
@@ -105,6 +106,7 @@ struct kg_engine {
   hipEvent_t ev_start[2] = {nullptr, nullptr}, ev_stop[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
   hipEvent_t ev_sum0[2] = {nullptr, nullptr}, ev_sum1[2] = {nullptr, nullptr};  // around kg_hist_sum_kernel
   hipEvent_t ev_walk[2] = {nullptr, nullptr};  // walk kernel finished, clock stamps copied (stream2 waits for it)
+  std::vector<hipEvent_t> ev_seg;  // [2][nseg - 1]: walk kernel of a launch segment but the last finished
   hipEvent_t ev_poke = nullptr;   // after the last SetKangaroo poke queued on stream2
   bool pokes_queued = false;      // pokes on stream2 that the next walk kernel must wait for
   u64 *X = nullptr, *Y = nullptr, *D = nullptr;
@@ -322,8 +324,8 @@ static int ring_follow_config(kg_engine *e) {
 // per launch buffer (`nbuf` of them) the jump-index history and the DP chains (one head per kangaroo slot, one link
 // per ring item; walk_kernel_stream.h).  kg_kick / kg_launch use two launch buffers, so that the history kernel of one
 // launch can run underneath the walk kernel of the next; kg_kick_static uses one.
-static size_t stream_ws_part(const kg_engine *e) {
-  return (size_t)WS_SLOT_WORDS * (size_t)e->K * (size_t)e->threads * sizeof(u32);
+static size_t stream_ws_part(const kg_engine *e) {  // the slots of ONE launch segment (all segments use the same ones)
+  return (size_t)WS_SLOT_WORDS * (size_t)e->K_seg * (size_t)e->threads * sizeof(u32);
 }
 static size_t stream_hist_part(const kg_engine *e) {  // 16-byte aligned
   return ((size_t)e->nb_run * (size_t)e->K * (size_t)e->threads + 15) & ~(size_t)15;
@@ -370,6 +372,8 @@ extern "C" int kg_destroy(kg_engine *e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->stream2) (void)hipStreamSynchronize(e->stream2);
   if (e->ev_poke) (void)hipEventDestroy(e->ev_poke);
+  for (hipEvent_t ev : e->ev_seg)
+    if (ev) (void)hipEventDestroy(ev);
   for (int b = 0; b < 2; ++b) {
     if (e->ev_walk[b]) (void)hipEventDestroy(e->ev_walk[b]);
     if (e->ev_sum0[b]) (void)hipEventDestroy(e->ev_sum0[b]);
@@ -431,20 +435,27 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
     k = std::min<u64>(std::max<u64>(k, 2), 1024);
     k += k & 1;
     // The streaming kernel addresses its workspace through ONE 32-bit buffer descriptor: 96 bytes per kangaroo slot
-    // must stay below 4 GiB, i.e. at most 44.7 M kangaroos per engine (2^32 / 96; 4.3 GB of herd state).  A larger herd
-    // is REFUSED rather than silently moved to the register-resident kernel, which is 25 % slower and spills
-    // (profiles/r02_kernel_resources.txt): the caller splits it over several engines on the device, as the
-    // reference's `-gpuId 0,0` does (core/kangaroo.cpp:780-786; tests/test_gpu_configs.py runs two engines on one
-    // GPU), or asks for KG_MODE_REG explicitly.  The reference's own limit is its int offset, ~178 M (engine.cu:17).
+    // must stay below 4 GiB, i.e. at most 44.7 M kangaroos per kernel launch.  A larger herd is walked in several LAUNCH
+    // SEGMENTS per Launch: segment s takes kangaroos s * K_seg .. (s + 1) * K_seg - 1 of every lane, the kernels run one
+    // after the other on the same workspace (the slots are scratch of one kernel launch), each with its own part of the
+    // jump-index history and of the DP chains.  Round 2 fell back to the slower, spilling register-resident kernel
+    // there.  The reference's own limit is its int offset, ~178 M kangaroos (engine.cu:17).
     const u64 lanes_k = ((e->n + k - 1) / k + WALK_BLOCK - 1) / WALK_BLOCK * WALK_BLOCK;
-    if (lanes_k * k * (u64)(WS_SLOT_WORDS * 4) >= (1ull << 32)) {
-      char msg[256];
-      snprintf(msg, sizeof msg, "kg_create: %llu kangaroos are beyond the streaming kernel's 4 GiB workspace (44.7 M per engine): "
-               "use several engines on the device or KG_MODE_REG", (unsigned long long)e->n);
+    const u64 limit = (tune && tune->ws_limit_bytes) ? tune->ws_limit_bytes : (1ull << 32);
+    const u64 slot_bytes = lanes_k * (u64)(WS_SLOT_WORDS * 4);  // workspace bytes of ONE kangaroo per lane
+    if (limit > (1ull << 32) || 2 * slot_bytes >= limit) {
       delete e;
-      return fail(KG_ERR_ARG, msg);
+      return fail(KG_ERR_ARG, "kg_create: kg_tuning.ws_limit_bytes must hold two kangaroos per lane and not exceed 4 GiB");
     }
-    e->K = (int)k;
+    // launch segments: as many kangaroos per lane as fit the descriptor, an even number
+    u64 kseg_max = (limit - 1) / slot_bytes;
+    kseg_max -= kseg_max & 1;
+    const u64 nseg = (k + kseg_max - 1) / kseg_max;
+    u64 kseg = (k + nseg - 1) / nseg;
+    kseg += kseg & 1;
+    e->nseg = (int)nseg;
+    e->K_seg = (int)kseg;
+    e->K = (int)(nseg * kseg);
   }
   if (!e->streaming) {
     e->K = want_k > 0 ? want_k : 16;
@@ -454,6 +465,7 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
     }
   }
   e->DW = 3;
+  if (!e->streaming) e->K_seg = e->K;
   const u64 per_lane = (e->n + e->K - 1) / e->K;
   const u64 blocks = (per_lane + WALK_BLOCK - 1) / WALK_BLOCK;
   if (blocks > 0x7FFFFFFFull) {
@@ -492,6 +504,8 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
     CRT(hipEventCreate(&e->ev_stop[b]));
     CRT(hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
   }
+  e->ev_seg.assign((size_t)2 * (e->nseg - 1), nullptr);
+  for (hipEvent_t &ev : e->ev_seg) CRT(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   const size_t plane_bytes = (size_t)e->cap * 4 * sizeof(u64);
   CRT(hipMalloc((void **)&e->X, plane_bytes));
   CRT(hipMalloc((void **)&e->Y, plane_bytes));
@@ -831,37 +845,52 @@ static int launch_walk(kg_engine *e, void *ws, int nbuf) {
     e->pokes_queued = false;
   }
   HIPCHK(hipMemsetAsync(e->count_dev + b, 0, sizeof(u32), sA));
+  a.p_base = 0;
   if (e->streaming) {
     const StreamWs w = stream_ws_at(e, ws, nbuf, nbuf > 1 ? b : 0);
-    StreamArgs sa;
-    sa.a = a;
-    sa.ws = w.slots;
-    sa.hist = w.hist;
-    sa.K = (u32)e->K;
-    sa.pace = w.pace;
-    sa.dp_head = w.dp_head;
-    sa.dp_link = w.dp_link;
-    HIPCHK(hipMemsetAsync(sa.pace, 0, stream_pace_part(), sA));
-    HIPCHK(hipMemsetAsync(sa.dp_head, 0xFF, stream_head_part(e), sA));  // DP_NONE
-    HIPCHK(hipEventRecord(e->ev_start[b], sA));
-    hipLaunchKernelGGL(g_stream_fn, dim3(e->grid), dim3(WALK_BLOCK), lds, sA, sa);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e->ev_stop[b], sA));
-    // clock stamps written by workgroup 0 behind the pacing table (the next launch clears the table: copy on sA)
-    HIPCHK(hipMemcpyAsync(e->count_host + 2 + b * PACE_TAIL, w.pace + PACE_KEYS * 4, PACE_TAIL * sizeof(u32),
-                          hipMemcpyDeviceToHost, sA));
-    HIPCHK(hipEventRecord(e->ev_walk[b], sA));
-    HIPCHK(hipStreamWaitEvent(sB, e->ev_walk[b], 0));
-    // distances: D += sum over the launch's jump-index history, and the distances of the launch's DP items
-    const u32 sum_grid = (u32)((e->cap / 2 + WALK_BLOCK - 1) / WALK_BLOCK);  // one thread per pair of slots and lane
-    HIPCHK(hipEventRecord(e->ev_sum0[b], sB));
-    if (e->DW == 3)
-      hipLaunchKernelGGL(kg_hist_sum_kernel<3>, dim3(sum_grid), dim3(WALK_BLOCK), 0, sB, sa.hist, e->jt, e->D,
-                         e->cap, e->n, e->threads, (u32)e->K, e->nb_run, sa.dp_head, sa.dp_link, e->out_dev[b]);
-    else
-      hipLaunchKernelGGL(kg_hist_sum_kernel<8>, dim3(sum_grid), dim3(WALK_BLOCK), 0, sB, sa.hist, e->jt, e->D,
-                         e->cap, e->n, e->threads, (u32)e->K, e->nb_run, sa.dp_head, sa.dp_link, e->out_dev[b]);
-    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(w.dp_head, 0xFF, stream_head_part(e), sA));  // DP_NONE
+    const u32 sum_grid = (u32)(((u64)(e->K_seg / 2) * e->threads + WALK_BLOCK - 1) / WALK_BLOCK);  // a thread per pair of slots and lane
+    const u64 seg_slots = (u64)e->K_seg * e->threads;  // kangaroo positions of one launch segment
+    for (int sg = 0; sg < e->nseg; ++sg) {
+      // launch segment sg: kangaroos sg * K_seg .. of every lane, i.e. positions [off, off + seg_slots)
+      const u64 off = (u64)sg * seg_slots;
+      StreamArgs sa;
+      sa.a = a;
+      sa.a.X = e->X + off;
+      sa.a.Y = e->Y + off;
+      sa.a.D = e->D + off;
+      sa.a.n = e->n > off ? e->n - off : 0;
+      sa.a.p_base = off;
+      sa.ws = w.slots;
+      sa.hist = w.hist + (size_t)sg * e->nb_run * seg_slots;
+      sa.K = (u32)e->K_seg;
+      sa.pace = w.pace;
+      sa.dp_head = w.dp_head + off;
+      sa.dp_link = w.dp_link;
+      HIPCHK(hipMemsetAsync(sa.pace, 0, stream_pace_part(), sA));
+      if (sg == 0) HIPCHK(hipEventRecord(e->ev_start[b], sA));
+      hipLaunchKernelGGL(g_stream_fn, dim3(e->grid), dim3(WALK_BLOCK), lds, sA, sa);
+      HIPCHK(hipGetLastError());
+      const bool last = sg == e->nseg - 1;
+      hipEvent_t walked = last ? e->ev_walk[b] : e->ev_seg[(size_t)b * (e->nseg - 1) + sg];
+      if (last) {
+        HIPCHK(hipEventRecord(e->ev_stop[b], sA));
+        // clock stamps written by workgroup 0 behind the pacing table (the next launch clears the table: copy on sA)
+        HIPCHK(hipMemcpyAsync(e->count_host + 2 + b * PACE_TAIL, w.pace + PACE_KEYS * 4, PACE_TAIL * sizeof(u32),
+                              hipMemcpyDeviceToHost, sA));
+      }
+      HIPCHK(hipEventRecord(walked, sA));
+      HIPCHK(hipStreamWaitEvent(sB, walked, 0));
+      // distances: D += sum over the segment's jump-index history, and the distances of its DP items
+      if (sg == 0) HIPCHK(hipEventRecord(e->ev_sum0[b], sB));
+      if (e->DW == 3)
+        hipLaunchKernelGGL(kg_hist_sum_kernel<3>, dim3(sum_grid), dim3(WALK_BLOCK), 0, sB, sa.hist, e->jt, sa.a.D,
+                           e->cap, sa.a.n, e->threads, (u32)e->K_seg, e->nb_run, sa.dp_head, sa.dp_link, e->out_dev[b]);
+      else
+        hipLaunchKernelGGL(kg_hist_sum_kernel<8>, dim3(sum_grid), dim3(WALK_BLOCK), 0, sB, sa.hist, e->jt, sa.a.D,
+                           e->cap, sa.a.n, e->threads, (u32)e->K_seg, e->nb_run, sa.dp_head, sa.dp_link, e->out_dev[b]);
+      HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipEventRecord(e->ev_sum1[b], sB));
   } else {
     HIPCHK(hipEventRecord(e->ev_start[b], sA));

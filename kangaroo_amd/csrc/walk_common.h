@@ -40,7 +40,8 @@ struct DpItemDev {  // 80 bytes, written to pinned host memory
 struct WalkArgs {
   u64 *X, *Y, *D;            // 4 planes each
   u64 cap;                   // plane stride (padded kangaroo count)
-  u64 n;                     // real kangaroo count
+  u64 n;                     // real kangaroo count (of this launch segment: positions p >= n are padding)
+  u64 p_base;                // position of this segment's first kangaroo in the whole herd: kIdx = p_base + p
   u32 threads;               // total threads (grid * block)
   u32 nb_run;                // steps per launch (NB_RUN)
   u32 dp_mask_hi, dp_mask_lo;

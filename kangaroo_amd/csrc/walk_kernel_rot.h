@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_rot(WalkArgs a) 
               add_dist_256<DW>(w, a.D, a.cap, p, delta[j]);
 #pragma unroll
               for (int i = 0; i < 8; ++i) it->d[i] = w[i];
-              it->kidx = p;
+              it->kidx = a.p_base + p;
             }
           }
         }

@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
             it->x[i] = xw.lo[i];
             it->x[4 + i] = xw.hi[i];
           }
-          it->kidx = p;
+          it->kidx = a.p_base + p;
           // the distance is filled in by kg_hist_sum_kernel: chain the item to its kangaroo.  Only this lane ever
           // touches the head of kangaroo p; the exchange is an atomic so that it is served by the L2 and never by
           // a stale line of this CU's vector cache
@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(WALK_BLOCK) kg_hist_sum_kernel(const unsigned 
   for (u32 i = threadIdx.x; i < NB_JUMP * DW; i += WALK_BLOCK) jdist[i] = jtab->dist[i / DW][i % DW];
   __syncthreads();
   const u64 q = (u64)blockIdx.x * WALK_BLOCK + threadIdx.x;  // pair * threads + lane
-  if (q >= cap / 2) return;
+  if (q >= (u64)(K >> 1) * threads) return;
   const u32 pair = (u32)(q / threads), lane = (u32)(q % threads);
   const unsigned short *col = (const unsigned short *)hist + q;  // + step * (K / 2) * threads
   const u64 step_stride = (u64)(K >> 1) * threads;

@@ -29,7 +29,7 @@ class _CItem(C.Structure):
 
 
 class _CTuning(C.Structure):
-    _fields_ = [("mode", C.c_int), ("k_per_lane", C.c_int), ("ring_max_items", C.c_uint32)]
+    _fields_ = [("mode", C.c_int), ("k_per_lane", C.c_int), ("ring_max_items", C.c_uint32), ("ws_limit_bytes", C.c_uint64)]
 
 
 MODE_AUTO, MODE_STREAM, MODE_REG = 0, 1, 2
@@ -136,15 +136,15 @@ def _limbs(v):
 class GPUEngine:
     """GPUEngine(nbThreadGroup, nbThreadPerGroup, gpuId, maxFound) — math/gpu/engine.cu:67-170."""
 
-    def __init__(self, nbThreadGroup, nbThreadPerGroup, gpuId, maxFound, mode=None, k_per_lane=0, ring_max=0):
-        """mode / k_per_lane / ring_max: kg_tuning (kg_create_tuned); mode is None, "stream" or "reg"; ring_max caps
-        the DP ring (items per launch), 0 = the engine's default."""
+    def __init__(self, nbThreadGroup, nbThreadPerGroup, gpuId, maxFound, mode=None, k_per_lane=0, ring_max=0, ws_limit=0):
+        """mode / k_per_lane / ring_max / ws_limit: kg_tuning (kg_create_tuned); mode is None, "stream" or "reg"; ring_max
+        caps the DP ring (items per launch), ws_limit the workspace bytes of one kernel launch (0 = the engine's defaults)."""
         self._L = load_library()
         self._h = C.c_void_p()
-        if mode is None and not k_per_lane and not ring_max:
+        if mode is None and not k_per_lane and not ring_max and not ws_limit:
             _chk(self._L.kg_create(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, C.byref(self._h)))
         else:
-            t = _CTuning({None: MODE_AUTO, "stream": MODE_STREAM, "reg": MODE_REG}[mode], int(k_per_lane or 0), int(ring_max or 0))
+            t = _CTuning({None: MODE_AUTO, "stream": MODE_STREAM, "reg": MODE_REG}[mode], int(k_per_lane or 0), int(ring_max or 0), int(ws_limit or 0))
             _chk(self._L.kg_create_tuned(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, C.byref(t), C.byref(self._h)))
         buf = C.create_string_buffer(256)
         _chk(self._L.kg_device_name(self._h, buf, 256))

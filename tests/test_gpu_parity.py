@@ -11,10 +11,10 @@ from gpu_common import dp_multiset, make_case, oracle_dps
 pytestmark = pytest.mark.gpu
 
 
-def _engine(groups, per_group, case, nb_run=None, k=None, mode=None, ring_max=0):
+def _engine(groups, per_group, case, nb_run=None, k=None, mode=None, ring_max=0, ws_limit=0):
     from kangaroo_amd import GPUEngine
 
-    e = GPUEngine(groups, per_group, 0, 65536 * 2, mode=mode, k_per_lane=k or 0, ring_max=ring_max)  # kg_create_tuned
+    e = GPUEngine(groups, per_group, 0, 65536 * 2, mode=mode, k_per_lane=k or 0, ring_max=ring_max, ws_limit=ws_limit)  # kg_create_tuned
     e.SetWildOffset(case["width"] >> 1)  # core/kangaroo.cpp:436
     e.SetParams(case["dp_mask"], case["jd"], case["jx"], case["jy"])
     if nb_run:
@@ -311,4 +311,75 @@ def test_dp_mask_lowered_while_a_launch_is_in_flight_grows_the_ring():
     assert e.lost == 0 and dp_multiset(r4) == oracle_dps(case, px, py, d, 24)
     gx, gy, gd = e.GetKangaroos()
     assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
+    e.close()
+
+
+def test_launch_segments_equal_one_launch():
+    """A herd whose streaming workspace exceeds what one kernel launch may address (4 GiB = 44.7 M kangaroos on the
+    hardware; here kg_tuning.ws_limit_bytes forces it on 16 384 kangaroos) is walked in several launch segments per
+    Launch: 12 kangaroos per lane as 3 segments of 4.  DPs (with their kIdx), the whole herd after three launches and a
+    SetKangaroo in between must equal the oracle's, exactly as with one segment."""
+    case = make_case(64, 128 * 2 * 64, seed=616, dp_bits=5)
+    lanes = 1536  # ceil(16384 / 12) rounded up to 256
+    e = _engine(2, 64, case, nb_run=40, k=12, mode="stream", ws_limit=4 * lanes * 96 + 1)
+    assert e.KernelInfo()["k_per_lane"] == 12
+    px, py, d = case["px"].copy(), case["py"].copy(), case["d"].copy()
+    e.callKernel()
+    r1 = e.Launch()
+    ref1 = oracle_dps(case, px, py, d, 40)
+    assert dp_multiset(r1) == ref1 and len(ref1) > 10000
+    # kangaroos of every segment report: kIdx covers the whole herd
+    assert {int(k) * 3 // (128 * 2 * 64) for k in r1["kIdx"]} == {0, 1, 2}
+    nx, ny, nd = K.create_herd(case["rng"], 64, case["width"], case["key"], 2, 1)
+    e.SetKangaroo(7, nx[0], ny[0], nd[0])          # first segment
+    e.SetKangaroo(16001, nx[1], ny[1], nd[1])      # last segment
+    assert dp_multiset(e.Launch()) == oracle_dps(case, px, py, d, 40)  # launch 2 ran on the old herd
+    px[7], py[7], d[7] = nx[0], ny[0], nd[0]
+    px[16001], py[16001], d[16001] = nx[1], ny[1], nd[1]
+    assert dp_multiset(e.Collect()) == oracle_dps(case, px, py, d, 40)
+    gx, gy, gd = e.GetKangaroos()
+    assert np.array_equal(gx, px) and np.array_equal(gy, py) and np.array_equal(gd, d)
+    e.close()
+    with pytest.raises(Exception) as ei:  # a limit that cannot hold two kangaroos per lane
+        _engine(2, 64, case, k=12, mode="stream", ws_limit=lanes * 96)
+    assert "ws_limit_bytes" in str(ei.value)
+
+
+def test_herd_beyond_one_descriptor_runs_in_segments():
+    """67 108 864 kangaroos (6.4 GB of state; the streaming workspace of one launch ends at 44.7 M): two launch segments
+    of 256 kangaroos per lane.  Round 2 ran such a herd on the spilling register-resident kernel.  Checked on a sample:
+    start points from the GPU herd kernel, 24 steps, re-walked by the oracle kangaroo by kangaroo (a walk only depends
+    on its own start), and every DP item of the sample."""
+    from kangaroo_amd import GPUEngine, host
+
+    e = GPUEngine(4096, 128, 0, 65536 * 2)
+    n = e.nbKangaroo
+    assert n == 1 << 26 and "stream" in e.KernelName() and e.KernelInfo()["k_per_lane"] == 512
+    jd, jx, jy, _ = K.create_jump_table(125)
+    width = (1 << 125) - 1
+    key = K.ec_mul_g(0x0A5B3C1D2E7F9081726354453627180F % width)
+    dist = host.herd_distances(host.Rng(99), 125, width, n, 0)
+    e.SetWildOffset(width >> 1)
+    dp_mask = 0xFFFC000000000000  # DP size 14
+    e.SetParams(dp_mask, jd, jx, jy)
+    e.SetNbRun(24)
+    e.HerdFromDistances(dist, key)
+    sx, sy, sd = e.GetKangaroos()
+    rnd = np.random.default_rng(3)
+    sample = np.unique(np.concatenate([rnd.integers(0, n, 3000), np.arange(0, 64), np.arange(n - 64, n),
+                                       np.arange(n // 2 - 64, n // 2 + 64)]))
+    ox, oy, od = (np.ascontiguousarray(a[sample]) for a in (sx, sy, sd))
+    del sx, sy, sd
+    e.callKernel()
+    items = e.Collect()
+    assert e.lost == 0 and abs(len(items) - n * 24 / 2 ** 14) < 6 * (n * 24 / 2 ** 14) ** 0.5
+    ref = K.walk(ox, oy, od, 24, dp_mask, jd, jx, jy)
+    gx, gy, gd = e.GetKangaroos()
+    assert np.array_equal(gx[sample], ox) and np.array_equal(gy[sample], oy) and np.array_equal(gd[sample], od)
+    want = sorted((int(sample[k]), x, dd) for _, k, x, dd in ref)
+    pos = {int(v): i for i, v in enumerate(sample)}
+    got = sorted(t for t in dp_multiset(items) if t[0] in pos)
+    assert got == want
+    # the two halves of the herd both report (kIdx below and above the segment boundary)
+    assert (items["kIdx"] < n // 2).any() and (items["kIdx"] >= n // 2).any()
     e.close()
