@@ -165,26 +165,29 @@ def test_72bit_solve_two_gpu_threads_one_table():
 
 def test_config5_multi_key_low_dp_two_threads_with_saves(tmp_path):
     """BASELINE config 5 in miniature, all at once: two keys in a row, DP = 8 (about one DP per kangaroo and launch),
-    two GPU threads feeding one table, and -w saves with the herds (GetKangaroos on both engines, table + 1 M
+    two GPU threads feeding one table, and -w saves with the herds (GetKangaroos on both engines, table + 262 144
     kangaroos on disk) while the search runs.  Nothing may be lost (a lost item raises), both keys must be found,
     and the last work file must describe the last key."""
-    lo = 1 << 60
-    privs = [lo + 0x00C0FFEE12345678 % (1 << 56), lo + 0x00DEADBEEF987654 % (1 << 56)]
+    lo = 1 << 70
+    bits = 58  # about 2^30 jumps per key: some 16 rounds of the two 131 072-kangaroo herds; the main loop polls every
+    # 2 ms, so that the first save request goes out during the first launches
+    privs = [lo + 0x0C0FFEE123456789 % (1 << bits), lo + 0x0DEADBEEF9876543 % (1 << bits)]
     pubs = [K.ec_mul_g(p) for p in privs]
     path = str(tmp_path / "c5.kg")
-    res = solve.solve_keys(lo, lo + (1 << 56) - 1, pubs, gpu_ids=(0, 0), grid=(32, 128), dp_bits=8, seed=31,
-                           work_file=path, save_period=0.0, max_launches=400)
+    res = solve.solve_keys(lo, lo + (1 << bits) - 1, pubs, gpu_ids=(0, 0), grid=(8, 128), dp_bits=8, seed=31,
+                           work_file=path, save_period=0.0, max_launches=4000, poll=0.002)
     assert [r[0] for r in res] == privs
     for _, st in res:
-        assert st["saves"] >= 1 and st["kangaroos"] == 2 * 128 * 32 * 128
+        print(st["saves"], st["launches"], st["dps"], st["table"], st["dead"], st["unstored"])
+        assert st["saves"] >= 1 and st["kangaroos"] == 2 * 128 * 8 * 128
         # every DP either went into the table, marked a dead kangaroo, or is the one that solved the key / arrived after it
         assert st["table"] + st["dead"] + st["unstored"] == st["dps"] and st["table"] > 100000
         assert 1 <= st["unstored"] < 20000
         assert all(t["launches"] > 0 for t in st["per_thread"])
     info = host.work_info(path)
-    assert info["dp_bits"] == 8 and info["kangaroos"] == 2 * 128 * 32 * 128 and info["items"] > 100000
-    assert info["range_start"] == lo and info["range_end"] == lo + (1 << 56) - 1
-    sv = host.Solver(lo, lo + (1 << 56) - 1, pubs[1])
+    assert info["dp_bits"] == 8 and info["kangaroos"] == 2 * 128 * 8 * 128 and info["items"] > 100000
+    assert info["range_start"] == lo and info["range_end"] == lo + (1 << bits) - 1
+    sv = host.Solver(lo, lo + (1 << bits) - 1, pubs[1])
     assert info["key"] == pubs[1] or info["key"] == sv.key  # the file carries the key as the reference writes it
 
 
