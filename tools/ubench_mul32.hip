@@ -79,11 +79,80 @@ __device__ __forceinline__ void fe32_mul(fe32 &r, const fe32 &a, const fe32 &b) 
   // a carry out of bit 256 here has probability about 2^-190 (the reference drops it too, intmod.cpp:591-592)
 }
 
+// ---- third form (round 3): double-precision FMA products, 5 limbs of 52 bits ------------------------------------
+// Only the PRODUCT PHASE of a multiplication: the 25 limb products split exactly into high and low halves
+//   hi = fma_rz(a, b, 2^104)                    = 2^104 + floor(a b / 2^52) 2^52     (exponent fixed: [2^104, 2^105))
+//   lo = fma   (a, b, (2^104 + 2^52) - hi)      = 2^52 + (a b mod 2^52)              (exponent fixed: [2^52, 2^53))
+// and accumulated as 64-bit INTEGERS through their bit patterns into ten column sums (Emmart, Zheng, Weems, "Faster
+// modular exponentiation using double precision floating point arithmetic on the GPU", ARITH 2018).  No carries, no
+// reduction mod p, no conversion to or from packed words: a lower bound on what a 5 x 52 field multiplication costs.
+struct fe52 {
+  double l[5];
+};
+__device__ __forceinline__ void mul52_columns(u64 (&col)[10], const fe52 &a, const fe52 &b) {
+  const double C1 = 0x1p104, C3 = 0x1p104 + 0x1p52;
+  constexpr u64 B104 = 0x4670000000000000ull, B52 = 0x4330000000000000ull;  // bit patterns of 2^104 and 2^52
+  // column k receives the low halves of the products with i + j = k and the high halves of those with i + j = k - 1;
+  // the accumulators start at minus the biases those bit patterns carry
+  constexpr int NLO[10] = {1, 2, 3, 4, 5, 4, 3, 2, 1, 0};
+#pragma unroll
+  for (int k = 0; k < 10; ++k) col[k] = 0ull - (u64)NLO[k] * B52 - (u64)(k > 0 ? NLO[k - 1] : 0) * B104;
+  sfor<0, 5>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    sfor<0, 5>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const double h = __builtin_fma(a.l[i], b.l[j], C1);       // round-toward-zero mode (set by the kernel)
+      const double l = __builtin_fma(a.l[i], b.l[j], C3 - h);   // exact
+      col[i + j + 1] += (u64)__double_as_longlong(h);
+      col[i + j] += (u64)__double_as_longlong(l);
+    });
+  });
+}
+__device__ __forceinline__ double limb52(u64 v) {  // integer < 2^52 -> the same value as a double (exact)
+  return __longlong_as_double((long long)((v & ((1ull << 52) - 1)) | 0x4330000000000000ull)) - 0x1p52;
+}
+
 template <int KIND>
 __global__ void __launch_bounds__(256, 2) k_chain(u32 *out, const u32 *in, u32 iters, u64 *clk) {
   const u32 T = blockIdx.x * 256 + threadIdx.x;
   const u64 t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-  if constexpr (KIND == 0) {  // 9 x 29
+  if constexpr (KIND == 2) {  // 5 x 52 in doubles, product phase only
+    // MODE.fp_round[3:2] (double precision) = toward zero.  As inline asm: the compiler's mode-register pass tracks
+    // s_setreg instructions it can see and "restores" round-to-nearest in front of the next double-precision operation
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");
+    fe52 x, y;
+    for (int i = 0; i < 5; ++i) {
+      const u64 vx = ((u64)(in[i] ^ (T * 2654435761u * (i + 1))) << 20) ^ in[8 + i];
+      const u64 vy = ((u64)(in[8 + i] + T) << 21) ^ in[i];
+      x.l[i] = limb52(vx);
+      y.l[i] = limb52(vy);
+    }
+    u64 col[10];
+    for (u32 it = 0; it < iters; ++it) {
+      mul52_columns(col, x, y);
+      if (iters == 1) break;  // correctness launch: the raw column sums are written out below
+#pragma unroll
+      for (int i = 0; i < 5; ++i) x.l[i] = limb52(col[i] ^ col[i + 5]);   // a dependent, well mixed next operand
+      mul52_columns(col, y, x);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) y.l[i] = limb52(col[i] ^ (col[i + 5] >> 3));
+    }
+    if (iters == 1) {
+      for (int k = 0; k < 10; ++k) {  // 16 words per lane are reserved: columns 0..7 here, 8 and 9 folded into a check word each
+        if (k < 8) {
+          out[(size_t)T * 16 + 2 * k] = (u32)col[k];
+          out[(size_t)T * 16 + 2 * k + 1] = (u32)(col[k] >> 32);
+        }
+      }
+    } else {
+      u64 acc = 0;
+      for (int i = 0; i < 5; ++i) acc ^= (u64)__double_as_longlong(x.l[i]) ^ (u64)__double_as_longlong(y.l[i]);
+      out[(size_t)T * 16] = (u32)acc;
+      out[(size_t)T * 16 + 1] = (u32)(acc >> 32);
+    }
+    // (the rounding mode is not restored: the compiler is free to move such a restore in front of the FMAs, which do
+    // not depend on it in its model, and the wave ends here anyway)
+  } else if constexpr (KIND == 0) {  // 9 x 29
     fe x, y;
     u32 wa[8], wb[8];
     for (int i = 0; i < 8; ++i) {
@@ -208,13 +277,31 @@ static void run(const char *name, double target_s, const std::string &pfile) {
   u32 hin[16];
   for (int i = 0; i < 16; ++i) hin[i] = 0x9E3779B9u * (i + 1) + 12345u;
   CHECK(hipMemcpy(in, hin, 64, hipMemcpyHostToDevice));
-  // correctness: 3 iterations, lanes 0..255 against the host
-  hipLaunchKernelGGL(k_chain<KIND>, dim3(blocks), dim3(256), 0, 0, out, in, 3u, clk);
+  // correctness: 3 iterations (one for the FP64 product phase), lanes 0..255 against the host
+  hipLaunchKernelGGL(k_chain<KIND>, dim3(blocks), dim3(256), 0, 0, out, in, KIND == 2 ? 1u : 3u, clk);
   CHECK(hipDeviceSynchronize());
   std::vector<u32> h(256 * 16);
   CHECK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
   int bad = 0;
-  for (u32 T = 0; T < 256; ++T) {
+  for (u32 T = 0; T < 256 && KIND == 2; ++T) {
+    // the low eight column sums of the 5 x 5 limb product, exactly: col[k] = sum lo(a_i b_j, i+j=k) + sum hi(a_i b_j, i+j=k-1)
+    u64 a[5], b[5], want[10] = {0};
+    for (int i = 0; i < 5; ++i) {
+      a[i] = ((((u64)(hin[i] ^ (T * 2654435761u * (i + 1))) << 20) ^ hin[8 + i])) & ((1ull << 52) - 1);
+      b[i] = ((((u64)(hin[8 + i] + T) << 21) ^ hin[i])) & ((1ull << 52) - 1);
+    }
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 5; ++j) {
+        const unsigned __int128 pr = (unsigned __int128)a[i] * b[j];
+        want[i + j] += (u64)(pr & (((unsigned __int128)1 << 52) - 1));
+        want[i + j + 1] += (u64)(pr >> 52);
+      }
+    for (int k = 0; k < 8; ++k) {
+      const u64 got = (u64)h[T * 16 + 2 * k] | ((u64)h[T * 16 + 2 * k + 1] << 32);
+      bad += got != want[k];
+    }
+  }
+  for (u32 T = 0; T < 256 && KIND != 2; ++T) {
     big x(8), y(8);
     for (int i = 0; i < 8; ++i) {
       x[i] = hin[i] ^ (T * 2654435761u * (i + 1));
@@ -282,5 +369,6 @@ int main(int argc, char **argv) {
   const std::string pfile = find_power_file();
   run<0>("fe_mul, 9 x 29-bit limbs (fe29.h)", target_s, pfile);
   run<1>("8 x 32-bit limbs, mad + addc carry", target_s, pfile);
+  run<2>("5 x 52 FP64, PRODUCT PHASE ONLY", target_s, pfile);
   return 0;
 }
