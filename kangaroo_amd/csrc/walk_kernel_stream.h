@@ -115,14 +115,26 @@ struct pk256 {
   u32x4 lo, hi;
 };
 // rows [ROW, ROW + 2) of slot id
+// KG_TIMING_NO_WS_LOADS / KG_TIMING_NO_WS_STORES: TIMING EXPERIMENTS ONLY (wrong results, never in the library): what the
+// workspace traffic of the pass loop costs, loads and stores apart (profiles/r03_levers.txt)
 template <int ROW>
 __device__ __forceinline__ void ws_load(pk256 &v, const ws_ref &w, u32 id) {
+#ifdef KG_TIMING_NO_WS_LOADS
+  v.lo = u32x4{id, w.off, (u32)ROW, id * 3u};
+  v.hi = u32x4{id ^ w.off, 7u, w.off, 1u};
+  asm volatile("" : "+v"(v.lo), "+v"(v.hi));
+  return;
+#endif
   const u32 base = (id * WS_ROWS + (u32)ROW) * w.row_bytes;
   v.lo = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.off, base, KG_WS_AUX_LD);
   v.hi = __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.off, base + w.row_bytes, KG_WS_AUX_LD);
 }
 template <int ROW>
 __device__ __forceinline__ void ws_store(const ws_ref &w, u32 id, const pk256 &v) {
+#ifdef KG_TIMING_NO_WS_STORES
+  asm volatile("" ::"v"(v.lo), "v"(v.hi));
+  return;
+#endif
   const u32 base = (id * WS_ROWS + (u32)ROW) * w.row_bytes;
   __builtin_amdgcn_raw_buffer_store_b128(v.lo, w.rs, w.off, base, KG_WS_AUX_ST);
   __builtin_amdgcn_raw_buffer_store_b128(v.hi, w.rs, w.off, base + w.row_bytes, KG_WS_AUX_ST);
