@@ -1041,9 +1041,9 @@ uint64_t kgh_solver_dump(const kgh_solver *s, uint64_t *out, uint64_t cap) {
 //   u64 totalWalk, then totalWalk x { px[32], py[32], d[32] }           storage/backup.cpp:389-410
 // maxItem is the capacity of the reference's std::vector; a table filled by single inserts has the next power of
 // two, which is what is written here (any value >= nbItem loads).
-// PARITY UNPINNED for the file as a whole: no work file written by the reference is available as a fixture
-// (its tests hold none and binaries built from it are not run here); the entry packing itself (Convert) is
-// pinned by the reference DP tables in tests/golden/reference_vectors.json.
+// PINNED (round 3): tests/golden/ref_work_r32_dp8.bin.gz was written by the reference's own Kangaroo::SaveWork
+// (oracle/ref_harness.cpp --savework); kgh_work_load reads it, kgh_work_save reproduces it byte for byte, and the
+// reference's LoadWork + FetchWalks read a file written here (tests/test_workfile.py).
 namespace {
 constexpr uint32_t HEADW_MAGIC = 0xFA6A8001u;
 constexpr uint32_t HASH_BUCKETS = 1u << 18;

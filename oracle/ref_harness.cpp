@@ -9,6 +9,8 @@
 // on a small known-key range and dumps the DP hash table it leaves behind.
 //
 // Usage: ref_harness <out.json>
+//        ref_harness --savework <out.bin> <out.json>   the reference's own Kangaroo::SaveWork writes a work file
+//        ref_harness --loadwork <in.bin> <out.json>    the reference's own LoadWork + FetchWalks read one
 // standard headers first, so that the access override below only touches kangaroo.h
 #include <algorithm>
 #include <array>
@@ -351,15 +353,111 @@ static void stepFixture(FILE *f, Ctx &c) {
   delete k;
 }
 
+static void dumpTable(FILE *f, Kangaroo *k) {
+  fprintf(f, "\"table\":[");
+  bool first = true;
+  for (uint32_t h = 0; h < HASH_SIZE; h++)
+    for (uint32_t i = 0; i < k->hashTable.E[h].nbItem; i++) {
+      const ENTRY *e = k->hashTable.GetEntry(h, i);
+      fprintf(f, "%s[%u,\"%s\",\"%s\"]", first ? "" : ",", h, hx4(e->x.i64).c_str(), hx4(e->d.i64).c_str());
+      first = false;
+    }
+  fprintf(f, "]");
+}
+
+// A work file written by the reference's own code (storage/backup.cpp:256-428, memory/hashtable.cpp:262-284): a real
+// SolveKeyCPU run on a range that does not start at 0 leaves its DP table behind, a fresh herd stands in for the
+// kangaroos of a parked thread, and Kangaroo::SaveWork(totalCount, totalTime, threads, nbThread) writes header, table
+// and kangaroos.  The JSON beside it holds the same state as the reference has it in memory.
+static int saveWorkFixture(Ctx &c, const char *binPath, const char *jsonPath) {
+  const int dp = 8, grp = 64, bits = 32;
+  std::string wf = binPath, none;
+  Kangaroo *k = new Kangaroo(c.secp, dp, false, wf, none, 60, true, false, 0.0, 3000, 17403, 3000, "", "/dev/null", false);
+  Int start, end, priv, w;
+  start.SetBase16((char *)"5000000000");
+  end.Set(&start);
+  w.SetInt32(1);
+  w.ShiftL(bits);
+  w.SubOne();
+  end.Add(&w);
+  priv.SetBase16((char *)"50B7E15163");
+  Point pub = c.secp->ComputePublicKey(&priv);
+  if (!k->SetSearchContext(start, end, pub, "savework")) return 2;
+  k->CreateJumpTable();
+  k->SetDP(dp);
+  k->CPU_GRP_SIZE = grp;
+  k->counters.fill(0);
+  k->nbCPUThread = 1;
+  k->nbGPUThread = 0;
+  rseed(2024);
+  TH_PARAM p;
+  p.obj = k;
+  p.threadId = 0;
+  p.isRunning = true;
+  p.hasStarted = false;
+  p.isWaiting = false;
+  p.nbKangaroo = grp;
+  k->endOfSearch = false;
+  k->SolveKeyCPU(&p);  // creates its own herd, builds the table, clears the herd when it ends
+  p.px.resize(grp);
+  p.py.resize(grp);
+  p.distance.resize(grp);
+  k->CreateHerd(grp, p.px.data(), p.py.data(), p.distance.data(), TAME);
+  p.isWaiting = true;  // the state SaveWork waits for (core/thread.cpp:36-42)
+  const uint64_t totalCount = k->counters[0];
+  const double totalTime = 12.625;
+  k->SaveWork(totalCount, totalTime, &p, 1);
+  FILE *f = fopen(jsonPath, "w");
+  if (!f) return 1;
+  fprintf(f, "{\"dp\":%d,\"rangeStart\":\"%s\",\"rangeEnd\":\"%s\",\"pubx\":\"%s\",\"puby\":\"%s\",\"priv\":\"%s\","
+             "\"totalCount\":%" PRIu64 ",\"totalTime\":%.6f,\"solved\":%s,\n",
+          dp, hx(start).c_str(), hx(end).c_str(), hx(pub.x).c_str(), hx(pub.y).c_str(), hx(priv).c_str(), totalCount,
+          totalTime, k->endOfSearch ? "true" : "false");
+  dumpTable(f, k);
+  fprintf(f, ",\n\"herd\":[");
+  for (int i = 0; i < grp; i++)
+    fprintf(f, "%s[\"%s\",\"%s\",\"%s\"]", i ? "," : "", hx(p.px[i]).c_str(), hx(p.py[i]).c_str(), hx(p.distance[i]).c_str());
+  fprintf(f, "]}\n");
+  fclose(f);
+  delete k;
+  return 0;
+}
+
+// The reference's own LoadWork + FetchWalks (storage/backup.cpp:101-150, memory/hashtable.cpp:306-324) read a work file
+// (one this repository's kgh_work_save wrote) and what they got is dumped.
+static int loadWorkDump(Ctx &c, const char *binPath, const char *jsonPath) {
+  Kangaroo *k = makeKangaroo(c, -1);
+  std::string fn = binPath;
+  if (!k->LoadWork(fn)) return 3;
+  const uint64_t n = k->nbLoadedWalk;
+  std::vector<Int> x(n ? n : 1), y(n ? n : 1), d(n ? n : 1);
+  if (n) k->FetchWalks(n, x.data(), y.data(), d.data());
+  FILE *f = fopen(jsonPath, "w");
+  if (!f) return 1;
+  fprintf(f, "{\"dp\":%d,\"rangeStart\":\"%s\",\"rangeEnd\":\"%s\",\"pubx\":\"%s\",\"puby\":\"%s\","
+             "\"totalCount\":%" PRIu64 ",\"totalTime\":%.6f,\"left\":%" PRIu64 ",\n",
+          k->initDPSize, hx(k->rangeStart).c_str(), hx(k->rangeEnd).c_str(), hx(k->keysToSearch[0].x).c_str(),
+          hx(k->keysToSearch[0].y).c_str(), k->offsetCount, k->offsetTime, k->nbLoadedWalk);
+  dumpTable(f, k);
+  fprintf(f, ",\n\"herd\":[");
+  for (uint64_t i = 0; i < n; i++)
+    fprintf(f, "%s[\"%s\",\"%s\",\"%s\"]", i ? "," : "", hx(x[i]).c_str(), hx(y[i]).c_str(), hx(d[i]).c_str());
+  fprintf(f, "]}\n");
+  fclose(f);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: %s out.json\n", argv[0]);
+    fprintf(stderr, "usage: %s out.json | --savework out.bin out.json | --loadwork in.bin out.json\n", argv[0]);
     return 1;
   }
   Timer::Init();
   Secp256K1 *secp = new Secp256K1();
   secp->Init();
   Ctx c{secp, ""};
+  if (argc == 4 && !strcmp(argv[1], "--savework")) return saveWorkFixture(c, argv[2], argv[3]);
+  if (argc == 4 && !strcmp(argv[1], "--loadwork")) return loadWorkDump(c, argv[2], argv[3]);
   FILE *f = fopen(argv[1], "w");
   if (!f) return 1;
   fprintf(f, "{\n");

@@ -1,12 +1,19 @@
 """Work file in the reference's HEADW layout (storage/backup.cpp:256-428, memory/hashtable.cpp:13-21,262-324).
 
-PARITY UNPINNED for the file as a whole: the reference's tests hold no work file and binaries built from the
-reference are not run in this project, so the layout is checked field by field against the offsets and sizes read
-from the reference's source.  The 32-byte entries themselves (HashTable::Convert packing) are pinned: the table
-saved here is the one that reproduces the reference's DP table in tests/test_host_lib.py."""
+PINNED (round 3): tests/golden/ref_work_r32_dp8.bin.gz is a work file written by the reference's own
+Kangaroo::SaveWork — oracle/ref_harness.cpp --savework, the reference's CPU translation units compiled where they lie
+(oracle/Makefile, `make -C oracle workfile`) — after a real SolveKeyCPU run, and ref_work_r32_dp8.json is the same state
+as the reference holds it in memory.  This repository's reader must read that file, its writer must reproduce it byte
+for byte, and — in the container that has the reference, where oracle/_ref/ref_harness exists — the reference's own
+LoadWork + FetchWalks must read a file written here.  The reference's tests hold no work file of their own."""
+import gzip
+import json
+import os
 import struct
+import subprocess
 
 import numpy as np
+import pytest
 
 import kgoracle as K
 from kangaroo_amd import host
@@ -91,3 +98,74 @@ def test_save_info_load_round_trip(golden, tmp_path):
     # empty file without kangaroos
     sv.save_work(path, 6)
     assert host.work_info(path)["kangaroos"] == 0
+
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+HARNESS = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "ref_harness")
+LOW = (1 << 128) - 1
+
+
+def _ref_file(tmp_path):
+    raw = gzip.open(os.path.join(GOLD, "ref_work_r32_dp8.bin.gz")).read()
+    path = str(tmp_path / "ref_work.bin")
+    open(path, "wb").write(raw)
+    return path, raw, json.load(open(os.path.join(GOLD, "ref_work_r32_dp8.json")))
+
+
+def test_reads_the_file_the_reference_wrote(tmp_path):
+    path, raw, j = _ref_file(tmp_path)
+    n = len(j["herd"])
+    assert host.work_info(path) == {
+        "dp_bits": j["dp"], "range_start": H(j["rangeStart"]), "range_end": H(j["rangeEnd"]),
+        "key": (H(j["pubx"]), H(j["puby"])), "total_count": j["totalCount"], "total_time": j["totalTime"],
+        "items": len(j["table"]), "kangaroos": n}
+    sv = host.Solver(H(j["rangeStart"]), H(j["rangeEnd"]), (H(j["pubx"]), H(j["puby"])))
+    px, py, d = sv.load_work(path, max_kangaroos=n + 7)
+    assert len(px) == n
+    got = [(host.to_int(px[i]), host.to_int(py[i]), host.to_int(d[i])) for i in range(n)]
+    assert got == [(H(x), H(y), H(dd)) for x, y, dd in j["herd"]]
+    # the file keeps 128 bits of x and the packed 128-bit distance of every entry (hashtable.cpp:13-21)
+    assert [(h, x & LOW, dd & LOW) for h, x, dd in sv.dump()] == sorted((h, H(x) & LOW, H(dd) & LOW) for h, x, dd in j["table"])
+    # the kangaroos of the file are on their tracks: P = d*G for the tame ones, d*G + (pub - rangeStart*G) for the wild ones
+    sx, sy = host.ec_mul_g(H(j["rangeStart"]))
+    key = host.ec_add((H(j["pubx"]), H(j["puby"])), (sx, K.P - sy))
+    for i, (x, y, dd) in enumerate(got):
+        pt = host.ec_mul_g(dd)
+        assert (x, y) == (pt if i % 2 == 0 else host.ec_add(pt, key))
+
+
+def test_writes_the_file_the_reference_wrote_byte_for_byte(tmp_path):
+    path, raw, j = _ref_file(tmp_path)
+    n = len(j["herd"])
+    sv = host.Solver(H(j["rangeStart"]), H(j["rangeEnd"]), (H(j["pubx"]), H(j["puby"])))
+    herd = sv.load_work(path, max_kangaroos=n)
+    out = str(tmp_path / "ours.bin")
+    sv.save_work(out, j["dp"], total_count=j["totalCount"], total_time=j["totalTime"], herd=herd)
+    assert open(out, "rb").read() == raw
+    # and from a table built DP by DP instead of loaded: same bytes (bucket capacities follow the reference's growth)
+    sv2 = host.Solver(H(j["rangeStart"]), H(j["rangeEnd"]), (H(j["pubx"]), H(j["puby"])))
+    for h, x, dd in j["table"]:
+        D = H(dd)
+        dist = D & ((1 << 126) - 1)
+        if (D >> 127) & 1:
+            dist = (-dist) % K.N
+        assert sv2.add(H(x), dist, (D >> 126) & 1) == 1
+    sv2.save_work(out, j["dp"], total_count=j["totalCount"], total_time=j["totalTime"], herd=herd)
+    assert open(out, "rb").read() == raw
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness is built only where the reference is")
+def test_the_reference_reads_the_file_written_here(golden, tmp_path):
+    s, sv = _filled_solver(golden, 1)                                     # range that starts at 2^44
+    n = 40
+    px, py, d = host.create_herd(host.Rng(5), sv.range_power, sv.range_width, sv.key, n, 0)
+    path, out = str(tmp_path / "ours.bin"), str(tmp_path / "ref_read.json")
+    sv.save_work(path, 6, total_count=987654321, total_time=3.5, herd=(px, py, d))
+    subprocess.run([HARNESS, "--loadwork", path, out], check=True, stdout=subprocess.DEVNULL, timeout=120)
+    j = json.load(open(out))
+    assert (j["dp"], H(j["rangeStart"]), H(j["rangeEnd"]), H(j["pubx"]), H(j["puby"]), j["totalCount"], j["totalTime"], j["left"]) == \
+        (6, H(s["rangeStart"]), H(s["rangeEnd"]), H(s["pubx"]), H(s["puby"]), 987654321, 3.5, 0)
+    assert [(H(x), H(y), H(dd)) for x, y, dd in j["herd"]] == \
+        [(host.to_int(px[i]), host.to_int(py[i]), host.to_int(d[i])) for i in range(n)]
+    assert sorted((h, H(x) & LOW, H(dd) & LOW) for h, x, dd in j["table"]) == \
+        sorted((h, H(x) & LOW, H(dd) & LOW) for h, x, dd in s["table"])
