@@ -991,7 +991,7 @@ static int unpack(kg_engine *e, int b, kg_item *items, uint32_t cap, uint32_t *n
     convert(0, take);
   } else {
     // low DP sizes: millions of items per launch (8.4 M at DP = 8 on the default grid), converted by a few threads
-    const u32 nt = std::min<u32>(8, std::max<u32>(1, std::thread::hardware_concurrency()));
+    const u32 nt = std::min<u32>(16, std::max<u32>(1, std::thread::hardware_concurrency()));
     const u32 per = (take + nt - 1) / nt;
     std::vector<std::thread> th;
     for (u32 t = 1; t < nt; ++t) th.emplace_back(convert, std::min(take, t * per), std::min(take, (t + 1) * per));

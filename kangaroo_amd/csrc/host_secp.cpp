@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -18,6 +19,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <random>
 #include <unordered_map>
@@ -606,18 +608,93 @@ struct Entry {
 // threads of one large batch and by the threads of several GPUs — while the per-x order of arrival is kept.
 constexpr int NSHARD = 256;
 constexpr u64 CELL_USED = 1ULL << 63;  // in Entry::d.v[3]: HashTable::Convert keeps only 62 bits of that limb
+// The cells of one shard: zero pages straight from the kernel (nothing to clear, and a table of several GB is not
+// touched before it is used), on transparent huge pages where the kernel grants them — a DP lands on a random cell of
+// a table far larger than what 4 KiB pages let the TLB cover, so with small pages every insert walks the page table.
+class CellArray {
+ public:
+  CellArray() = default;
+  explicit CellArray(size_t n) : n_(n) {
+    if (!n) return;
+    const size_t bytes = n * sizeof(Entry);
+    if (bytes >= MAP_MIN && thp_granted()) {
+      // over-allocate so that the array can start on a 2 MiB boundary, then give the slack back
+      const size_t len = bytes + HUGE_SZ;
+      void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (m == MAP_FAILED) throw std::bad_alloc();
+      const uintptr_t a = ((uintptr_t)m + HUGE_SZ - 1) & ~(uintptr_t)(HUGE_SZ - 1);
+      if (a > (uintptr_t)m) munmap(m, a - (uintptr_t)m);
+      const size_t tail = ((uintptr_t)m + len) - (a + bytes);
+      if (tail) munmap((void *)(a + bytes), tail);
+      madvise((void *)a, bytes, MADV_HUGEPAGE);
+      p_ = (Entry *)a;
+      mapped_ = bytes;
+    } else {
+      p_ = (Entry *)calloc(n, sizeof(Entry));
+      if (!p_) throw std::bad_alloc();
+    }
+  }
+  CellArray(const CellArray &) = delete;
+  CellArray &operator=(const CellArray &) = delete;
+  ~CellArray() { release(); }
+  void swap(CellArray &o) {
+    std::swap(p_, o.p_);
+    std::swap(n_, o.n_);
+    std::swap(mapped_, o.mapped_);
+  }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  Entry &operator[](size_t i) { return p_[i]; }
+  const Entry &operator[](size_t i) const { return p_[i]; }
+  const Entry *begin() const { return p_; }
+  const Entry *end() const { return p_ + n_; }
+
+ private:
+  static constexpr size_t HUGE_SZ = 2u << 20;
+  // below one huge page a shard's array comes from the heap
+  static constexpr size_t MAP_MIN = 2u << 20;
+  // Fresh mmap'd memory on 4 KiB pages is the slowest way to get a table (one fault per page from 16 threads at once:
+  // measured 10 x slower than calloc's recycled heap on the MI355X box), so the mapping is used only where the kernel
+  // grants huge pages on request.
+  static bool thp_granted() {
+    static const bool yes = [] {
+      char buf[128] = {0};
+      FILE *f = fopen("/sys/kernel/mm/transparent_hugepage/enabled", "r");
+      if (!f) return false;
+      const size_t n = fread(buf, 1, sizeof buf - 1, f);
+      fclose(f);
+      buf[n] = 0;
+      return strstr(buf, "[always]") != nullptr || strstr(buf, "[madvise]") != nullptr;
+    }();
+    return yes;
+  }
+  void release() {
+    if (mapped_) munmap(p_, mapped_);
+    else free(p_);
+    p_ = nullptr;
+    n_ = mapped_ = 0;
+  }
+  Entry *p_ = nullptr;
+  size_t n_ = 0, mapped_ = 0;
+};
+
 struct Shard {
+  static constexpr size_t FIRST_MAPPED = (2u << 20) / sizeof(Entry);
   mutable std::mutex mu;
   // One 64-byte cell per slot and nothing else (the reference's ENTRY is 64 bytes too, kangaroo.h:303-306): the key
   // is read back from the entry — x limbs 0 and 1 and the bucket number h = x.limb2 & 0x3FFFF — and bit 63 of
   // d.limb3 marks a used cell.
-  std::vector<Entry> cells;
+  CellArray cells;
   size_t used = 0;
   static bool occupied(const Entry &c) { return (c.d.v[3] & CELL_USED) != 0; }
   static Key128 key_of(const Entry &c) { return Key128{c.x.v[2] & 0x3FFFF, c.x.v[0], c.x.v[1]}; }
   void grow() {
-    const size_t ncap = cells.empty() ? 1024 : cells.size() * 2;
-    std::vector<Entry> nc(ncap, Entry{U256{{0, 0, 0, 0}}, U256{{0, 0, 0, 0}}});
+    // 64 KiB from the heap first (small tables stay small), then straight to one huge page, then doubling: the sizes in
+    // between would each be fresh 4 KiB pages from the C library, and faulting those in costs more than the inserts
+    const size_t ncap = cells.empty() ? 1024 : cells.size() < FIRST_MAPPED ? FIRST_MAPPED : cells.size() * 2;
+    CellArray nc(ncap);
+    // a cell's new home is its old home or that plus the old size: one scan of the old array fills the new one in two
+    // ascending streams
     for (const Entry &c : cells)
       if (occupied(c)) {
         size_t j = Key128Hash()(key_of(c)) & (ncap - 1);
@@ -916,8 +993,15 @@ int kgh_solver_add_items(kgh_solver *s, const void *items, uint32_t n, uint32_t 
   //    consecutive slices, counted and scattered slice by slice
   const int nslice = nthreads;
   const uint32_t per = (n + nslice - 1) / nslice;
-  std::vector<uint32_t> start(NSHARD + 1, 0), order(n);
-  std::vector<uint8_t> sid(n);
+  // staging that outlives the call (one set per calling thread, i.e. per GPU): at 8.4 M items a launch these are 42 MB,
+  // and fresh pages for them on every call cost more than filling them
+  static thread_local std::vector<uint32_t> order_tl;
+  static thread_local std::vector<uint8_t> sid_tl;
+  if (order_tl.size() < n) order_tl.resize(n);
+  if (sid_tl.size() < n) sid_tl.resize(n);
+  uint32_t *const order = order_tl.data();  // the workers must see THIS thread's arrays: a lambda that named the
+  uint8_t *const sid = sid_tl.data();       // thread_local vectors would get the executing thread's own
+  std::vector<uint32_t> start(NSHARD + 1, 0);
   std::vector<std::vector<uint32_t>> cnt(nslice, std::vector<uint32_t>(NSHARD, 0)), off(nslice, std::vector<uint32_t>(NSHARD, 0));
   s->pool.parallel_for(nslice, [&](int t) {
     const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
@@ -954,31 +1038,55 @@ int kgh_solver_add_items(kgh_solver *s, const void *items, uint32_t n, uint32_t 
   std::vector<std::vector<uint32_t>> sdead(NSHARD);
   std::vector<std::vector<Coll>> scoll(NSHARD);
   s->pool.parallel_for(NSHARD, [&](int sh) {
-    // The shard's items go in runs of up to RUN under ONE hold of the shard's mutex: first the home slots of the whole
-    // run are prefetched (the table is far larger than the caches: every insert is a miss otherwise), then the run is
-    // inserted in arrival order.  A grow() inside a run only makes the remaining prefetches useless.
-    constexpr uint32_t RUN = 32;
+    // Every access of this loop would be a cache miss: the shard's items lie ~256 items apart in the caller's array
+    // (two lines each), and each lands on a random cell of a table far larger than the caches.  So the loop is a
+    // software pipeline over runs of RUN items: the items of run r+2 are prefetched, run r+1 is converted and its home
+    // cells are prefetched, run r is inserted.  A chunk of CHUNK runs goes under ONE hold of the shard's mutex (other
+    // producers wait that long at most); arrival order inside the shard is kept.  A grow() inside a chunk only makes the
+    // prefetches in flight useless.
+    constexpr uint32_t RUN = 16, CHUNK = 32;
     Shard &shard = s->shard[sh];
-    for (uint32_t q0 = start[sh]; q0 < start[sh + 1]; q0 += RUN) {
-      const uint32_t q1 = std::min<uint32_t>(q0 + RUN, start[sh + 1]);
-      Key128 keys[RUN];
-      Entry ents[RUN];
+    const uint32_t lo = start[sh], hi = start[sh + 1];
+    auto fetch_items = [&](uint32_t q0) {
+      const uint32_t q1 = std::min<uint32_t>(q0 + RUN, hi);
+      for (uint32_t q = q0; q < q1; ++q) {
+        const char *p = (const char *)&it[order[q]];
+        __builtin_prefetch(p, 0, 0);
+        __builtin_prefetch(p + sizeof(kg_item) - 1, 0, 0);
+      }
+    };
+    Key128 keys[2][RUN];
+    Entry ents[2][RUN];
+    auto convert = [&](uint32_t q0, int b) {  // shard.mu held: reads the table's size
+      const uint32_t q1 = std::min<uint32_t>(q0 + RUN, hi);
       for (uint32_t q = q0; q < q1; ++q) {
         const uint32_t i = order[q];
-        ht_convert(load(it[i].x), load(it[i].d), (uint32_t)(it[i].kIdx & 1), keys[q - q0], ents[q - q0]);
+        ht_convert(load(it[i].x), load(it[i].d), (uint32_t)(it[i].kIdx & 1), keys[b][q - q0], ents[b][q - q0]);
       }
-      std::lock_guard<std::mutex> lock(shard.mu);
       if (!shard.cells.empty()) {
         const size_t mask = shard.cells.size() - 1;
-        for (uint32_t q = q0; q < q1; ++q) __builtin_prefetch(&shard.cells[Key128Hash()(keys[q - q0]) & mask], 1, 0);
+        for (uint32_t q = q0; q < q1; ++q) __builtin_prefetch(&shard.cells[Key128Hash()(keys[b][q - q0]) & mask], 1, 0);
       }
-      for (uint32_t q = q0; q < q1; ++q) {
-        const uint32_t i = order[q];
-        U256 d0;
-        uint32_t t0;
-        const int r = shard_insert_locked(s, shard, keys[q - q0], ents[q - q0], (uint32_t)(it[i].kIdx & 1), &d0, &t0);
-        if (r == 0) sdead[sh].push_back(i);
-        else if (r == 3) scoll[sh].push_back(Coll{i, d0, t0});
+    };
+    fetch_items(lo);
+    fetch_items(lo + RUN);
+    for (uint32_t c0 = lo; c0 < hi; c0 += RUN * CHUNK) {
+      const uint32_t c1 = std::min<uint32_t>(c0 + RUN * CHUNK, hi);
+      std::lock_guard<std::mutex> lock(shard.mu);
+      int b = 0;
+      convert(c0, b);
+      for (uint32_t q0 = c0; q0 < c1; q0 += RUN, b ^= 1) {
+        const uint32_t q1 = std::min<uint32_t>(q0 + RUN, c1);
+        if (q0 + 2 * RUN < hi) fetch_items(q0 + 2 * RUN);
+        if (q1 < c1) convert(q1, b ^ 1);
+        for (uint32_t q = q0; q < q1; ++q) {
+          const uint32_t i = order[q];
+          U256 d0;
+          uint32_t t0;
+          const int r = shard_insert_locked(s, shard, keys[b][q - q0], ents[b][q - q0], (uint32_t)(it[i].kIdx & 1), &d0, &t0);
+          if (r == 0) sdead[sh].push_back(i);
+          else if (r == 3) scoll[sh].push_back(Coll{i, d0, t0});
+        }
       }
     }
   });

@@ -125,3 +125,29 @@ def test_every_item_is_accounted_for_when_the_key_is_found():
         sv.add_items(_items(500, 10))       # after the key: nothing is stored any more
         assert sv.add(1, 2, 0) == 2
         assert sv.table_size + sv.dead + sv.unstored == n + 501
+
+
+def test_table_keeps_every_dp_through_its_growth_steps():
+    """5.6 M distinct DPs take every shard from its first 64 KiB array to one huge page and on to the first doubling of a
+    mapped array (host_secp.cpp CellArray / Shard::grow); handed in a second time, every one of them must be found again
+    (an exact duplicate: a dead kangaroo, nothing stored)."""
+    pub = K.ec_mul_g(0x1234567)
+    sv = host.Solver(0, (1 << 64) - 1, pub)
+    sv.set_threads(8)
+    per, batches = 1_400_000, 4
+    data = []
+    for b in range(batches):
+        rnd = np.random.default_rng(1000 + b)
+        it = np.zeros(per, dtype=ITEM_DTYPE)
+        it["x"] = rnd.integers(0, 1 << 63, size=(per, 4), dtype=np.uint64)
+        it["x"][:, 1] = (it["x"][:, 1] & np.uint64(0x0FFFFFFFFFFFFFFF)) | np.uint64(b << 60)  # distinct across batches
+        it["d"][:, :2] = rnd.integers(0, 1 << 62, size=(per, 2), dtype=np.uint64)
+        it["kIdx"] = rnd.integers(0, 1 << 20, size=per, dtype=np.uint64)
+        data.append(it)
+        rc, dead = sv.add_items(it)
+        assert rc == 0 and len(dead) == 0
+    assert sv.table_size == per * batches and sv.dead == 0
+    for it in data:
+        rc, dead = sv.add_items(it)
+        assert rc == 0 and len(dead) == per and dead[0] == 0 and dead[-1] == per - 1
+    assert sv.table_size == per * batches and sv.dead == per * batches and sv.unstored == 0

@@ -29,11 +29,13 @@ eng.callKernel()
 eng.Launch()  # warm-up launch, its DPs are dropped
 t0 = time.perf_counter()
 n_dp = 0
-t_ins = 0.0
+t_ins = t_launch = 0.0
 dead_total = 0
 kernel_ms, sum_ms = [], []
 for i in range(launches):
+    t1 = time.perf_counter()
     items = eng.Launch(copy=False)
+    t_launch += time.perf_counter() - t1
     kernel_ms.append(eng.LastKernelMs())
     sum_ms.append(eng.LastSumKernelMs())
     n_dp += len(items)
@@ -53,5 +55,6 @@ print(f"walk kernel ms per launch               : median {sorted(kernel_ms)[len(
 print(f"history kernel ms (2nd stream, overlaps) : median {sorted(sum_ms)[len(sum_ms) // 2]:.2f}")
 print(f"wall ms per launch                       : {1e3 * dt / launches:.2f}")
 print(f"DPs drained                             : {n_dp} = {n_dp / dt / 1e6:.2f} M/s, lost {eng.lost}")
+print(f"Launch call (wait + item unpack)        : {1e3 * t_launch / launches:.2f} ms per launch; add_items {1e3 * t_ins / launches:.2f} ms per launch")
 print(f"table insert rate (add_items only)      : {n_dp / t_ins / 1e6:.2f} M/s, table {sv.table_size}, dead {dead_total}")
 eng.close()
