@@ -686,6 +686,11 @@ struct Shard {
   // d.limb3 marks a used cell.
   CellArray cells;
   size_t used = 0;
+  // A shard doubles when it is this full (in 1/256).  The shards of one table fill at the same pace; with ONE limit all
+  // 256 would double during the same batch — at 84 M DPs that batch takes 250 ms instead of 50, longer than the GPU's
+  // queued launch lasts.  The solver spreads the limits from 40 % to 65 %, so that the doublings are spread over the
+  // batches in which the table grows by a factor 1.6.
+  uint32_t max_load_256 = 154;
   static bool occupied(const Entry &c) { return (c.d.v[3] & CELL_USED) != 0; }
   static Key128 key_of(const Entry &c) { return Key128{c.x.v[2] & 0x3FFFF, c.x.v[0], c.x.v[1]}; }
   void grow() {
@@ -705,7 +710,7 @@ struct Shard {
   }
   // returns the cell of key, inserting e if absent; *existed tells which.  e.x must carry the key (key_of(e) == key).
   Entry *find_or_insert(const Key128 &key, const Entry &e, bool *existed) {
-    if ((used + 1) * 5 > cells.size() * 3) grow();
+    if ((used + 1) * 256 > cells.size() * max_load_256) grow();
     size_t j = Key128Hash()(key) & (cells.size() - 1);
     while (occupied(cells[j])) {
       if (key_of(cells[j]) == key) {
@@ -934,6 +939,7 @@ static int add_one(kgh_solver *s, const U256 &x, const U256 &d, u64 k_idx) {
 kgh_solver *kgh_solver_new(const uint64_t range_start[4], const uint64_t range_end[4], const uint64_t pub_x[4],
                            const uint64_t pub_y[4]) {
   kgh_solver *s = new kgh_solver();
+  for (int i = 0; i < NSHARD; ++i) s->shard[i].max_load_256 = 102 + (uint32_t)(i * 64 / (NSHARD - 1));  // 40 % .. 65 %
   s->range_start = load(range_start);
   s->range_end = load(range_end);
   sub_to(s->width, s->range_end, s->range_start);
