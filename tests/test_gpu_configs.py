@@ -263,3 +263,17 @@ def test_config3_80bit_solve_two_gpu_threads_one_table():
     assert all(t["launches"] > 0 and t["dps"] > 0 for t in st["per_thread"])
     assert st["table"] + st["dead"] + st["unstored"] == st["dps"]
     assert st["jumps"] < 16 * 2 * (1 << 40)
+
+
+@pytest.mark.timeout(500)
+def test_config3_80bit_solve_at_dp20():
+    """BASELINE config 3 with the DP size it names: an 80-bit known key at DP = 20.  With 20 DP bits the herd has to be
+    small for the DP overhead (kangaroos x 2^20 jumps) to stay near the 2^41 jumps of the search itself: 2^20 kangaroos
+    (grid 128 x 64), one engine.  2^40.7 jumps, 1.7 M DPs, 110 s at 16 G jumps/s (profiles/r03_solves.txt)."""
+    priv = (0xD1B54A32D192ED03C0FFEE1234567890ABCDEF % (1 << 79)) | (1 << 79)
+    pub = K.ec_mul_g(priv)
+    found, st = solve.solve_key(0, (1 << 80) - 1, pub, grid=(128, 64), dp_bits=20, seed=11, max_launches=30000)
+    print(st)
+    assert found == priv and st["dp_bits"] == 20 and st["kangaroos"] == 1 << 20
+    assert st["table"] + st["dead"] + st.get("unstored", 0) == st["dps"]
+    assert st["jumps"] < 8 * 2 * (1 << 40)
