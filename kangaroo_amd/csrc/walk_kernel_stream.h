@@ -77,7 +77,27 @@ constexpr u32 PACE_TAIL = 4;
 #ifndef KG_JT_NEG
 #define KG_JT_NEG 1
 #endif
-constexpr int SJT_STRIDE = KG_JT_NEG ? 27 : JT_STRIDE;  // words of an LDS row (odd: spreads the banks)
+// MEASUREMENT VARIANT, off in the library (profiles/r03_levers.txt): 1 = the three groups of a row start on 16-byte
+// boundaries (row of 36 words) and are read with two ds_read_b128 and one ds_read_b32 each instead of ds_read2_b32 pairs.
+#ifndef KG_JT_WIDE
+#define KG_JT_WIDE 0
+#endif
+constexpr int SJT_GROUP = (KG_JT_NEG && KG_JT_WIDE) ? 12 : 9;  // words from one group of a row to the next
+constexpr int SJT_STRIDE = KG_JT_NEG ? (KG_JT_WIDE ? 36 : 27) : JT_STRIDE;  // words of an LDS row (27: odd, spreads the banks)
+// the nine limbs of one group of a row
+__device__ __forceinline__ void jt_load9(fe &r, const u32 *g) {
+#if KG_JT_NEG && KG_JT_WIDE
+  typedef u32 v4 __attribute__((ext_vector_type(4)));
+  const v4 *q = (const v4 *)__builtin_assume_aligned(g, 16);
+  const v4 a = q[0], b = q[1];
+  r.l[0] = a[0]; r.l[1] = a[1]; r.l[2] = a[2]; r.l[3] = a[3];
+  r.l[4] = b[0]; r.l[5] = b[1]; r.l[6] = b[2]; r.l[7] = b[3];
+  r.l[8] = g[8];
+#else
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = g[i];
+#endif
+}
 // MEASUREMENT VARIANT, off in the library (profiles/r03_levers.txt): 1 = ONE inversion per workgroup and step, computed
 // on ONE lane.  The inverting wave first folds the 64 per-lane products of the workgroup into one with a product tree
 // across its lanes (through LDS, KG_INV_TREE_LEVELS levels), inverts on the surviving lanes with every other lane
@@ -198,8 +218,8 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     u32 row = i / 18, col = i % 18;
     const u32 v = a.jt->pxy[row][col];
 #if KG_JT_NEG
-    jt[row * SJT_STRIDE + col] = fe_b2(col % 9) - v;              // 2p' - jPx | 2p' - jPy
-    if (col < 9) jt[row * SJT_STRIDE + 18 + col] = fe_b4(col) - v;  // 4p' - jPx
+    jt[row * SJT_STRIDE + (col / 9) * SJT_GROUP + col % 9] = fe_b2(col % 9) - v;  // 2p' - jPx | 2p' - jPy
+    if (col < 9) jt[row * SJT_STRIDE + 2 * SJT_GROUP + col] = fe_b4(col) - v;       // 4p' - jPx
 #else
     jt[row * SJT_STRIDE + col] = v;
 #endif
@@ -235,8 +255,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     fe_unpack(x, xw);
     const u32 *row = jt + (x.l[0] & (NB_JUMP - 1)) * SJT_STRIDE;
     fe jx, dx;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) jx.l[i] = row[i];
+    jt_load9(jx, row);
 #if KG_JT_NEG
     fe_add_lifted(dx, x, jx);
 #else
@@ -260,8 +279,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   // point (and, for the second kangaroo of a pair, the running product), reports a distinguished point
   auto jump = [&](const fe &x, const fe &y, const fe &dxi, const fe &jx, const u32 *row, u32 id, u32 run, bool with_p) {
     fe jy;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) jy.l[i] = row[9 + i];
+    jt_load9(jy, row + SJT_GROUP);
     fe dy, s, p2, rx, tt, ry;
 #if KG_JT_NEG
     fe_add_lifted(dy, y, jy);
@@ -269,8 +287,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     fe_sqr(p2, s);
     {
       fe c4;  // 4p' - jPx, fetched where it is needed: nothing of the jump point stays in registers across the multiplications
-#pragma unroll
-      for (int i = 0; i < 9; ++i) c4.l[i] = row[18 + i];
+      jt_load9(c4, row + 2 * SJT_GROUP);
       fe_add_lifted_sub(rx, p2, c4, x);
     }
 #else
@@ -291,8 +308,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     {
       const u32 *row2 = jt + (rx.l[0] & (NB_JUMP - 1)) * SJT_STRIDE;
       fe jx2, dx2;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) jx2.l[i] = row2[i];
+      jt_load9(jx2, row2);
 #if KG_JT_NEG
       fe_add_lifted(dx2, rx, jx2);
 #else
@@ -506,11 +522,8 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       hist_run[(u64)(idB >> 1) * threads] = (unsigned short)(asc ? (jmpA | (jmpB << 8)) : (jmpB | (jmpA << 8)));
       const u32 *rowA = jt + jmpA * SJT_STRIDE, *rowB = jt + jmpB * SJT_STRIDE;
       fe jxA, jxB, dxA, dxB, dxiA, dxiB;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        jxA.l[i] = rowA[i];
-        jxB.l[i] = rowB[i];
-      }
+      jt_load9(jxA, rowA);
+      jt_load9(jxB, rowB);
 #if KG_JT_NEG
       fe_add_lifted(dxA, xA, jxA);
       fe_add_lifted(dxB, xB, jxB);
