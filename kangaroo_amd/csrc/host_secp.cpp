@@ -825,7 +825,7 @@ struct kgh_solver {
   // items handed in, always.
   std::atomic<u64> unstored{0};
   int threads = 0;  // threads working on a large batch, the caller included (0: hardware concurrency, capped at 16)
-  WorkPool pool;
+  mutable WorkPool pool;  // also serves kgh_work_save, which takes the solver const
 };
 static inline int shard_of(const Key128 &k) { return (int)((k.lo * 0x9E3779B97F4A7C15ULL) >> 56); }
 
@@ -979,11 +979,99 @@ void kgh_solver_set_threads(kgh_solver *s, int threads) { s->threads = threads <
 // shard.  In the threaded path every DP of the batch is inserted even if one of them solves the key.
 constexpr uint32_t PAR_BATCH = 8192;
 
+}  // extern "C": templates follow
+
+// Cuts the indices 0 .. n-1 of a batch by shard, arrival order kept inside each shard: order[start[sh] .. start[sh+1])
+// are the indices of shard sh, ascending.  key_lo(i) = limb 0 of item i's x.  The batch is cut into nslice consecutive
+// slices, counted and scattered slice by slice on the pool.
+template <class KeyLo>
+static void bucket_by_shard(WorkPool &pool, int nslice, uint32_t n, KeyLo key_lo, uint32_t *order, uint8_t *sid,
+                            std::vector<uint32_t> &start) {
+  const uint32_t per = (n + nslice - 1) / nslice;
+  std::vector<std::vector<uint32_t>> cnt(nslice, std::vector<uint32_t>(NSHARD, 0)), off(nslice, std::vector<uint32_t>(NSHARD, 0));
+  pool.parallel_for(nslice, [&](int t) {
+    const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
+    for (uint32_t i = lo; i < hi; ++i) {
+      Key128 k;
+      k.lo = key_lo(i);
+      const int sh = shard_of(k);
+      sid[i] = (uint8_t)sh;
+      cnt[t][sh]++;
+    }
+  });
+  start.assign(NSHARD + 1, 0);
+  uint32_t run = 0;  // offsets: shard-major, slice-minor (slices are consecutive, so this is arrival order)
+  for (int sh = 0; sh < NSHARD; ++sh) {
+    start[sh] = run;
+    for (int t = 0; t < nslice; ++t) {
+      off[t][sh] = run;
+      run += cnt[t][sh];
+    }
+  }
+  start[NSHARD] = run;
+  pool.parallel_for(nslice, [&](int t) {
+    const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
+    for (uint32_t i = lo; i < hi; ++i) order[off[t][sid[i]]++] = i;
+  });
+}
+
+// The items order[lo .. hi) of ONE shard go into it.  Every access of this loop would be a cache miss: the shard's
+// items lie ~256 items apart in the caller's array, and each lands on a random cell of a table far larger than the
+// caches.  So the loop is a software pipeline over runs of RUN items: the items of run r+2 are prefetched, run r+1 is
+// converted and its home cells are prefetched, run r is inserted.  A chunk of CHUNK runs goes under ONE hold of the
+// shard's mutex (other producers wait that long at most); arrival order inside the shard is kept.  A grow() inside a
+// chunk only makes the prefetches in flight useless.
+//   addr(i): address of item i (item_bytes long);  conv(i, key, entry): HashTable::Convert of item i;
+//   sink(i, key, entry): inserts it, called with the shard's mutex held.
+template <class Addr, class Conv, class Sink>
+static void shard_pipeline(Shard &shard, const uint32_t *order, uint32_t lo, uint32_t hi, size_t item_bytes, Addr addr, Conv conv,
+                           Sink sink) {
+  constexpr uint32_t RUN = 16, CHUNK = 32;
+  auto fetch_items = [&](uint32_t q0) {
+    const uint32_t q1 = std::min<uint32_t>(q0 + RUN, hi);
+    for (uint32_t q = q0; q < q1; ++q) {
+      const char *p = (const char *)addr(order[q]);
+      __builtin_prefetch(p, 0, 0);
+      __builtin_prefetch(p + item_bytes - 1, 0, 0);
+    }
+  };
+  Key128 keys[2][RUN];
+  Entry ents[2][RUN];
+  auto convert = [&](uint32_t q0, int b) {  // shard.mu held: reads the table's size
+    const uint32_t q1 = std::min<uint32_t>(q0 + RUN, hi);
+    for (uint32_t q = q0; q < q1; ++q) conv(order[q], keys[b][q - q0], ents[b][q - q0]);
+    if (!shard.cells.empty()) {
+      const size_t mask = shard.cells.size() - 1;
+      for (uint32_t q = q0; q < q1; ++q) __builtin_prefetch(&shard.cells[Key128Hash()(keys[b][q - q0]) & mask], 1, 0);
+    }
+  };
+  fetch_items(lo);
+  fetch_items(lo + RUN);
+  for (uint32_t c0 = lo; c0 < hi; c0 += RUN * CHUNK) {
+    const uint32_t c1 = std::min<uint32_t>(c0 + RUN * CHUNK, hi);
+    std::lock_guard<std::mutex> lock(shard.mu);
+    int b = 0;
+    convert(c0, b);
+    for (uint32_t q0 = c0; q0 < c1; q0 += RUN, b ^= 1) {
+      const uint32_t q1 = std::min<uint32_t>(q0 + RUN, c1);
+      if (q0 + 2 * RUN < hi) fetch_items(q0 + 2 * RUN);
+      if (q1 < c1) convert(q1, b ^ 1);
+      for (uint32_t q = q0; q < q1; ++q) sink(order[q], keys[b][q - q0], ents[b][q - q0]);
+    }
+  }
+}
+
+static int solver_threads(const kgh_solver *s) {
+  const int n = s->threads > 0 ? s->threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 16u);
+  return n < 1 ? 1 : n;
+}
+
+extern "C" {
+
 int kgh_solver_add_items(kgh_solver *s, const void *items, uint32_t n, uint32_t *dead, uint32_t *n_dead) {
   const kg_item *it = (const kg_item *)items;
   uint32_t nd = 0;
-  int nthreads = s->threads > 0 ? s->threads : (int)std::min<unsigned>(std::thread::hardware_concurrency(), 16u);
-  if (nthreads < 1) nthreads = 1;
+  const int nthreads = solver_threads(s);
   if (n < PAR_BATCH || nthreads == 1) {
     uint32_t i = 0;
     for (; i < n && !s->found; ++i) {
@@ -995,46 +1083,16 @@ int kgh_solver_add_items(kgh_solver *s, const void *items, uint32_t n, uint32_t 
     return s->found ? 2 : 0;
   }
   s->pool.ensure(nthreads - 1);  // the calling thread is the nthreads-th worker
-  // 1. bucket the item indices by shard, keeping arrival order inside each shard: the batch is cut into nslice
-  //    consecutive slices, counted and scattered slice by slice
-  const int nslice = nthreads;
-  const uint32_t per = (n + nslice - 1) / nslice;
-  // staging that outlives the call (one set per calling thread, i.e. per GPU): at 8.4 M items a launch these are 42 MB,
-  // and fresh pages for them on every call cost more than filling them
+  // 1. bucket the item indices by shard.  Staging that outlives the call (one set per calling thread, i.e. per GPU): at
+  //    8.4 M items a launch these are 42 MB, and fresh pages for them on every call cost more than filling them
   static thread_local std::vector<uint32_t> order_tl;
   static thread_local std::vector<uint8_t> sid_tl;
   if (order_tl.size() < n) order_tl.resize(n);
   if (sid_tl.size() < n) sid_tl.resize(n);
   uint32_t *const order = order_tl.data();  // the workers must see THIS thread's arrays: a lambda that named the
   uint8_t *const sid = sid_tl.data();       // thread_local vectors would get the executing thread's own
-  std::vector<uint32_t> start(NSHARD + 1, 0);
-  std::vector<std::vector<uint32_t>> cnt(nslice, std::vector<uint32_t>(NSHARD, 0)), off(nslice, std::vector<uint32_t>(NSHARD, 0));
-  s->pool.parallel_for(nslice, [&](int t) {
-    const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
-    for (uint32_t i = lo; i < hi; ++i) {
-      Key128 k;
-      k.lo = it[i].x[0];
-      const int sh = shard_of(k);
-      sid[i] = (uint8_t)sh;
-      cnt[t][sh]++;
-    }
-  });
-  {
-    // offsets: shard-major, slice-minor (slices are consecutive, so this is arrival order)
-    uint32_t run = 0;
-    for (int sh = 0; sh < NSHARD; ++sh) {
-      start[sh] = run;
-      for (int t = 0; t < nslice; ++t) {
-        off[t][sh] = run;
-        run += cnt[t][sh];
-      }
-    }
-    start[NSHARD] = run;
-  }
-  s->pool.parallel_for(nslice, [&](int t) {
-    const uint32_t lo = std::min<uint64_t>((uint64_t)t * per, n), hi = std::min<uint64_t>((uint64_t)(t + 1) * per, n);
-    for (uint32_t i = lo; i < hi; ++i) order[off[t][sid[i]]++] = i;
-  });
+  std::vector<uint32_t> start;
+  bucket_by_shard(s->pool, nthreads, n, [&](uint32_t i) { return it[i].x[0]; }, order, sid, start);
   // 2. shards in parallel; dead kangaroos and tame/wild collisions are recorded per shard
   struct Coll {
     uint32_t idx;
@@ -1044,57 +1102,17 @@ int kgh_solver_add_items(kgh_solver *s, const void *items, uint32_t n, uint32_t 
   std::vector<std::vector<uint32_t>> sdead(NSHARD);
   std::vector<std::vector<Coll>> scoll(NSHARD);
   s->pool.parallel_for(NSHARD, [&](int sh) {
-    // Every access of this loop would be a cache miss: the shard's items lie ~256 items apart in the caller's array
-    // (two lines each), and each lands on a random cell of a table far larger than the caches.  So the loop is a
-    // software pipeline over runs of RUN items: the items of run r+2 are prefetched, run r+1 is converted and its home
-    // cells are prefetched, run r is inserted.  A chunk of CHUNK runs goes under ONE hold of the shard's mutex (other
-    // producers wait that long at most); arrival order inside the shard is kept.  A grow() inside a chunk only makes the
-    // prefetches in flight useless.
-    constexpr uint32_t RUN = 16, CHUNK = 32;
     Shard &shard = s->shard[sh];
-    const uint32_t lo = start[sh], hi = start[sh + 1];
-    auto fetch_items = [&](uint32_t q0) {
-      const uint32_t q1 = std::min<uint32_t>(q0 + RUN, hi);
-      for (uint32_t q = q0; q < q1; ++q) {
-        const char *p = (const char *)&it[order[q]];
-        __builtin_prefetch(p, 0, 0);
-        __builtin_prefetch(p + sizeof(kg_item) - 1, 0, 0);
-      }
-    };
-    Key128 keys[2][RUN];
-    Entry ents[2][RUN];
-    auto convert = [&](uint32_t q0, int b) {  // shard.mu held: reads the table's size
-      const uint32_t q1 = std::min<uint32_t>(q0 + RUN, hi);
-      for (uint32_t q = q0; q < q1; ++q) {
-        const uint32_t i = order[q];
-        ht_convert(load(it[i].x), load(it[i].d), (uint32_t)(it[i].kIdx & 1), keys[b][q - q0], ents[b][q - q0]);
-      }
-      if (!shard.cells.empty()) {
-        const size_t mask = shard.cells.size() - 1;
-        for (uint32_t q = q0; q < q1; ++q) __builtin_prefetch(&shard.cells[Key128Hash()(keys[b][q - q0]) & mask], 1, 0);
-      }
-    };
-    fetch_items(lo);
-    fetch_items(lo + RUN);
-    for (uint32_t c0 = lo; c0 < hi; c0 += RUN * CHUNK) {
-      const uint32_t c1 = std::min<uint32_t>(c0 + RUN * CHUNK, hi);
-      std::lock_guard<std::mutex> lock(shard.mu);
-      int b = 0;
-      convert(c0, b);
-      for (uint32_t q0 = c0; q0 < c1; q0 += RUN, b ^= 1) {
-        const uint32_t q1 = std::min<uint32_t>(q0 + RUN, c1);
-        if (q0 + 2 * RUN < hi) fetch_items(q0 + 2 * RUN);
-        if (q1 < c1) convert(q1, b ^ 1);
-        for (uint32_t q = q0; q < q1; ++q) {
-          const uint32_t i = order[q];
+    shard_pipeline(
+        shard, order, start[sh], start[sh + 1], sizeof(kg_item), [&](uint32_t i) { return (const void *)&it[i]; },
+        [&](uint32_t i, Key128 &key, Entry &e) { ht_convert(load(it[i].x), load(it[i].d), (uint32_t)(it[i].kIdx & 1), key, e); },
+        [&](uint32_t i, const Key128 &key, const Entry &e) {
           U256 d0;
           uint32_t t0;
-          const int r = shard_insert_locked(s, shard, keys[b][q - q0], ents[b][q - q0], (uint32_t)(it[i].kIdx & 1), &d0, &t0);
+          const int r = shard_insert_locked(s, shard, key, e, (uint32_t)(it[i].kIdx & 1), &d0, &t0);
           if (r == 0) sdead[sh].push_back(i);
           else if (r == 3) scoll[sh].push_back(Coll{i, d0, t0});
-        }
-      }
-    }
+        });
   });
   // 3. collisions between herds, in arrival order (EC arithmetic, rare)
   std::vector<Coll> coll;
@@ -1177,39 +1195,77 @@ int kgh_work_save(const kgh_solver *s, const char *path, uint32_t dp_size, uint6
   bool ok = wr(f, &HEADW_MAGIC, 4) && wr(f, &version, 4) && wr(f, &dp_size, 4) && wr(f, s->range_start.v, 32) &&
             wr(f, s->range_end.v, 32) && wr(f, s->pub.x.v, 32) && wr(f, s->pub.y.v, 32) && wr(f, &total_count, 8) &&
             wr(f, &total_time, 8);
-  // gather the shards into the reference's 2^18 buckets.  Each shard is copied out under its mutex in ONE scan (the
-  // reference saves with every worker parked, storage/backup.cpp:327-345; this must also be safe if a producer is
-  // still inserting: a concurrent grow() reallocates the cells), the counting sort runs on the copy.
+  // Gather the shards into the reference's 2^18 buckets, on the solver's worker pool (round 3: a save of 49 M entries
+  // took 37 s on one thread, with every GPU thread parked for as long).  Each shard is copied out under its mutex in
+  // ONE scan (the reference saves with every worker parked, storage/backup.cpp:327-345; this must also be safe if a
+  // producer is still inserting: a concurrent grow() reallocates the cells).  The copies are cut into 256 partitions
+  // of 1024 consecutive buckets; every partition is sorted by (bucket, x) and laid out as it goes into the file.
   struct Snap {
     uint32_t h;
     FileEntry e;
   };
-  std::vector<Snap> snap;
-  for (const Shard &sh : s->shard) {
+  constexpr int NPART = 256, PART_SHIFT = 10;  // HASH_BUCKETS = NPART << PART_SHIFT
+  const int nthreads = solver_threads(s);
+  s->pool.ensure(nthreads - 1);
+  std::vector<std::vector<Snap>> per(NSHARD);
+  std::vector<std::vector<uint64_t>> off(NSHARD, std::vector<uint64_t>(NPART, 0));
+  s->pool.parallel_for(NSHARD, [&](int i) {
+    const Shard &sh = s->shard[i];
     std::lock_guard<std::mutex> lock(sh.mu);
-    snap.reserve(snap.size() + sh.used);
+    per[i].reserve(sh.used);
     for (const Entry &c : sh.cells)
-      if (Shard::occupied(c)) snap.push_back(Snap{(uint32_t)Shard::key_of(c).h, FileEntry{{c.x.v[0], c.x.v[1]}, {c.d.v[0], c.d.v[1]}}});
-  }
-  std::vector<uint32_t> cnt(HASH_BUCKETS + 1, 0);
-  for (const Snap &q : snap) cnt[q.h + 1]++;
-  for (uint32_t h = 0; h < HASH_BUCKETS; ++h) cnt[h + 1] += cnt[h];
-  std::vector<FileEntry> all(cnt[HASH_BUCKETS]);
+      if (Shard::occupied(c)) {
+        const uint32_t h = (uint32_t)Shard::key_of(c).h;
+        per[i].push_back(Snap{h, FileEntry{{c.x.v[0], c.x.v[1]}, {c.d.v[0], c.d.v[1]}}});
+        off[i][h >> PART_SHIFT]++;
+      }
+  });
+  std::vector<uint64_t> pstart(NPART + 1, 0);
   {
-    std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
-    for (const Snap &q : snap) all[pos[q.h]++] = q.e;
-  }
-  std::vector<Snap>().swap(snap);
-  for (uint32_t h = 0; h < HASH_BUCKETS && ok; ++h) {
-    FileEntry *b = all.data() + cnt[h];
-    const uint32_t nb = cnt[h + 1] - cnt[h];
-    std::sort(b, b + nb, [](const FileEntry &l, const FileEntry &r) { return l.x[1] != r.x[1] ? l.x[1] < r.x[1] : l.x[0] < r.x[0]; });
-    uint32_t cap = 0;
-    if (nb) {
-      cap = 1;
-      while (cap < nb) cap <<= 1;
+    uint64_t run = 0;  // partition-major, shard-minor
+    for (int p = 0; p < NPART; ++p) {
+      pstart[p] = run;
+      for (int i = 0; i < NSHARD; ++i) {
+        const uint64_t c = off[i][p];
+        off[i][p] = run;
+        run += c;
+      }
     }
-    ok = wr(f, &nb, 4) && wr(f, &cap, 4) && (nb == 0 || wr(f, b, (size_t)nb * sizeof(FileEntry)));
+    pstart[NPART] = run;
+  }
+  std::vector<Snap> parted(pstart[NPART]);
+  s->pool.parallel_for(NSHARD, [&](int i) {
+    for (const Snap &q : per[i]) parted[off[i][q.h >> PART_SHIFT]++] = q;
+    std::vector<Snap>().swap(per[i]);
+  });
+  std::vector<std::vector<char>> image(NPART);  // the partitions as they lie in the file
+  s->pool.parallel_for(NPART, [&](int p) {
+    Snap *b = parted.data() + pstart[p], *e = parted.data() + pstart[p + 1];
+    std::sort(b, e, [](const Snap &l, const Snap &r) {
+      return l.h != r.h ? l.h < r.h : l.e.x[1] != r.e.x[1] ? l.e.x[1] < r.e.x[1] : l.e.x[0] < r.e.x[0];
+    });
+    std::vector<char> &out = image[p];
+    out.resize(((size_t)8 << PART_SHIFT) + (size_t)(e - b) * sizeof(FileEntry));
+    char *w = out.data();
+    for (uint32_t h = (uint32_t)p << PART_SHIFT; h < ((uint32_t)p + 1) << PART_SHIFT; ++h) {
+      const Snap *q = b;
+      while (q < e && q->h == h) ++q;
+      const uint32_t nb = (uint32_t)(q - b);
+      uint32_t cap = 0;  // what the reference's vector holds after nb single inserts
+      if (nb) {
+        cap = 1;
+        while (cap < nb) cap <<= 1;
+      }
+      memcpy(w, &nb, 4);
+      memcpy(w + 4, &cap, 4);
+      w += 8;
+      for (; b < q; ++b, w += sizeof(FileEntry)) memcpy(w, &b->e, sizeof(FileEntry));
+    }
+  });
+  std::vector<Snap>().swap(parted);
+  for (int p = 0; p < NPART && ok; ++p) {
+    ok = wr(f, image[p].data(), image[p].size());
+    std::vector<char>().swap(image[p]);
   }
   const uint64_t walks = (px && py && d) ? n_kangaroo : 0;
   ok = ok && wr(f, &walks, 8);
@@ -1264,24 +1320,53 @@ int kgh_work_load(kgh_solver *s, const char *path, uint64_t *px, uint64_t *py, u
     fclose(f);
     return -5;  // another range or key
   }
+  // The buckets are read in order; every LOAD_CHUNK entries go into the table on the solver's worker pool, cut by shard
+  // like a batch of DPs (HashTable::LoadTable reads entry by entry, memory/hashtable.cpp:306-320).
+  struct Rec {
+    uint32_t h;
+    FileEntry e;
+  };
+  constexpr size_t LOAD_CHUNK = 8u << 20;
+  const int nthreads = solver_threads(s);
+  s->pool.ensure(nthreads - 1);
+  std::vector<Rec> recs;
   std::vector<FileEntry> buf;
+  std::vector<uint32_t> order, start;
+  std::vector<uint8_t> sid;
+  auto flush = [&]() {
+    const uint32_t n = (uint32_t)recs.size();
+    if (!n) return;
+    order.resize(n);
+    sid.resize(n);
+    bucket_by_shard(s->pool, nthreads, n, [&](uint32_t i) { return recs[i].e.x[0]; }, order.data(), sid.data(), start);
+    s->pool.parallel_for(NSHARD, [&](int sh) {
+      Shard &shard = s->shard[sh];
+      shard_pipeline(
+          shard, order.data(), start[sh], start[sh + 1], sizeof(Rec), [&](uint32_t i) { return (const void *)&recs[i]; },
+          [&](uint32_t i, Key128 &key, Entry &e) {
+            const Rec &r = recs[i];
+            key = Key128{(u64)r.h, r.e.x[0], r.e.x[1]};
+            e.x = U256{{r.e.x[0], r.e.x[1], (u64)r.h, 0}};  // the file keeps 128 bits of x; limb 2 carries the bucket number
+            e.d = U256{{r.e.d[0], r.e.d[1], 0, 0}};
+          },
+          [&](uint32_t, const Key128 &key, const Entry &e) {
+            bool existed;
+            shard.find_or_insert(key, e, &existed);
+          });
+    });
+    recs.clear();
+  };
   for (uint32_t h = 0; h < HASH_BUCKETS && ok; ++h) {
     uint32_t nb, capb;
     ok = rd(f, &nb, 4) && rd(f, &capb, 4);
     if (!ok || !nb) continue;
     buf.resize(nb);
     ok = rd(f, buf.data(), (size_t)nb * sizeof(FileEntry));
-    for (uint32_t i = 0; i < nb && ok; ++i) {
-      Key128 key{(u64)h, buf[i].x[0], buf[i].x[1]};
-      Entry e;
-      e.x = U256{{buf[i].x[0], buf[i].x[1], (u64)h, 0}};  // the file keeps 128 bits of x; limb 2 carries the bucket number
-      e.d = U256{{buf[i].d[0], buf[i].d[1], 0, 0}};
-      Shard &sh = s->shard[shard_of(key)];
-      std::lock_guard<std::mutex> lock(sh.mu);
-      bool existed;
-      sh.find_or_insert(key, e, &existed);
-    }
+    if (!ok) break;
+    for (uint32_t i = 0; i < nb; ++i) recs.push_back(Rec{h, buf[i]});
+    if (recs.size() >= LOAD_CHUNK) flush();
   }
+  if (ok) flush();
   ok = ok && rd(f, &walks, 8);
   uint64_t got = 0;
   for (; ok && got < walks && got < cap && px && py && d; ++got)

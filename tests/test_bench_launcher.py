@@ -37,11 +37,14 @@ def test_under_a_launcher_world_must_match_gpus():
 
 def test_torchrun_style_environment_two_ranks():
     """As the driver launches it: one process per rank with RANK / WORLD_SIZE / MASTER_* set."""
-    env = dict(_clean_env(), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
-    procs = [subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--plumbing-only", "--grid", "2,2", "--steps", "5"],
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                              text=True) for r in range(2)]
-    outs = [p.communicate(timeout=280) for p in procs]
+    for attempt in range(3):  # the port is picked by bind-and-close: another process may take it before rank 0 binds it
+        env = dict(_clean_env(), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+        procs = [subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--plumbing-only", "--grid", "2,2", "--steps", "5"],
+                                  env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                  text=True) for r in range(2)]
+        outs = [p.communicate(timeout=280) for p in procs]
+        if all(p.returncode == 0 for p in procs) or not any("address already in use" in e.lower() or "EADDRINUSE" in e for _, e in outs):
+            break
     assert all(p.returncode == 0 for p in procs), outs
     json_lines = [l for o, _ in outs for l in o.splitlines() if l.startswith("{")]
     assert len(json_lines) == 1
