@@ -169,3 +169,36 @@ def test_the_reference_reads_the_file_written_here(golden, tmp_path):
         [(host.to_int(px[i]), host.to_int(py[i]), host.to_int(d[i])) for i in range(n)]
     assert sorted((h, H(x) & LOW, H(dd) & LOW) for h, x, dd in j["table"]) == \
         sorted((h, H(x) & LOW, H(dd) & LOW) for h, x, dd in s["table"])
+
+
+def test_large_table_round_trip_through_the_worker_pool(tmp_path):
+    """120 000 random DPs (every shard, every partition of the file): saved and loaded on the solver's worker pool, the
+    loaded table equals the saved one entry for entry, and saving it again gives the same bytes."""
+    from kangaroo_amd.engine import ITEM_DTYPE
+
+    n = 120_000
+    rnd = np.random.default_rng(77)
+    it = np.zeros(n, dtype=ITEM_DTYPE)
+    it["x"] = rnd.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    it["d"][:, :2] = rnd.integers(0, 1 << 62, size=(n, 2), dtype=np.uint64)
+    it["d"][::3, 3] = np.uint64(0xFFFFFFFFFFFFFFFF)          # some negative distances (mod n), HashTable::Convert's sign bit
+    it["d"][::3, 2] = np.uint64(0xFFFFFFFFFFFFFFFE)
+    it["kIdx"] = rnd.integers(0, 1 << 20, size=n, dtype=np.uint64)
+    pub = K.ec_mul_g(0x1234567)
+    sv = host.Solver(0, (1 << 64) - 1, pub)
+    sv.set_threads(8)
+    rc, dead = sv.add_items(it)
+    assert rc == 0 and len(dead) == 0 and sv.table_size == n
+    a, b = str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    sv.save_work(a, 9, total_count=5, total_time=0.5)
+    assert host.work_info(a)["items"] == n
+    sv2 = host.Solver(0, (1 << 64) - 1, pub)
+    sv2.set_threads(8)
+    sv2.load_work(a)
+    assert sv2.table_size == n
+    low = lambda t: sorted((h, x & LOW, dd & LOW) for h, x, dd in t)  # the file keeps the low 128 bits of x
+    assert low(sv2.dump()) == low(sv.dump())
+    sv2.save_work(b, 9, total_count=5, total_time=0.5)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    rc, dead = sv2.add_items(it)                              # every DP is found again in the loaded table
+    assert len(dead) == n and sv2.table_size == n
