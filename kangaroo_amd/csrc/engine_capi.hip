@@ -432,8 +432,8 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
     // handles kangaroos in pairs)
     const u64 lanes = (u64)e->cus * 4 * 64 * (u64)KG_STREAM_W;
     u64 k = want_k > 0 ? (u64)want_k : std::max<u64>((e->n + lanes - 1) / lanes, 4);
-    k = std::min<u64>(std::max<u64>(k, 2), 1024);
-    k += k & 1;
+    k = std::min<u64>(std::max<u64>(k, WS_GROUP), 1024);
+    k = (k + WS_GROUP - 1) / WS_GROUP * WS_GROUP;
     // The streaming kernel addresses its workspace through ONE 32-bit buffer descriptor: 96 bytes per kangaroo slot
     // must stay below 4 GiB, i.e. at most 44.7 M kangaroos per kernel launch.  A larger herd is walked in several LAUNCH
     // SEGMENTS per Launch: segment s takes kangaroos s * K_seg .. (s + 1) * K_seg - 1 of every lane, the kernels run one
@@ -443,16 +443,16 @@ extern "C" int kg_create_tuned(int gpu_id, int groups, int per_group, uint32_t m
     const u64 lanes_k = ((e->n + k - 1) / k + WALK_BLOCK - 1) / WALK_BLOCK * WALK_BLOCK;
     const u64 limit = (tune && tune->ws_limit_bytes) ? tune->ws_limit_bytes : (1ull << 32);
     const u64 slot_bytes = lanes_k * (u64)(WS_SLOT_WORDS * 4);  // workspace bytes of ONE kangaroo per lane
-    if (limit > (1ull << 32) || 2 * slot_bytes >= limit) {
+    if (limit > (1ull << 32) || WS_GROUP * slot_bytes >= limit) {
       delete e;
       return fail(KG_ERR_ARG, "kg_create: kg_tuning.ws_limit_bytes must hold two kangaroos per lane and not exceed 4 GiB");
     }
     // launch segments: as many kangaroos per lane as fit the descriptor, an even number
     u64 kseg_max = (limit - 1) / slot_bytes;
-    kseg_max -= kseg_max & 1;
+    kseg_max -= kseg_max % WS_GROUP;
     const u64 nseg = (k + kseg_max - 1) / kseg_max;
     u64 kseg = (k + nseg - 1) / nseg;
-    kseg += kseg & 1;
+    kseg = (kseg + WS_GROUP - 1) / WS_GROUP * WS_GROUP;
     e->nseg = (int)nseg;
     e->K_seg = (int)kseg;
     e->K = (int)(nseg * kseg);

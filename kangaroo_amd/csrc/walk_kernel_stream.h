@@ -69,6 +69,17 @@ constexpr u32 PACE_TAIL = 4;
 #ifndef KG_WS_PAIRS
 #define KG_WS_PAIRS 1
 #endif
+// 1 (needs KG_WS_PAIRS): kangaroos go in QUADS (A, B, C, D) and only D stores the running product: q_C = q_D * dx_D and
+// q_B = q_C * dx_C are recomputed (11 multiplications per quad instead of 10), 8 B less read and 8 B less written per
+// jump.  Stores are what this kernel pays most for (profiles/r03_levers.txt: skipping every other product store alone is
+// worth 4 %).  The loop still runs pair by pair (one body, the instruction cache holds it); K is a multiple of 4.
+#ifndef KG_WS_QUADS
+#define KG_WS_QUADS 0
+#endif
+#if KG_WS_QUADS && !KG_WS_PAIRS
+#error "KG_WS_QUADS needs KG_WS_PAIRS"
+#endif
+constexpr u32 WS_GROUP = KG_WS_QUADS ? 4 : 2;  // kangaroos per lane come in multiples of this
 // 1: the LDS copy of the jump table holds the subtrahends already lifted and negated — per row 2p' - jPx, 2p' - jPy and
 // 4p' - jPx (p' = the limb-lifted multiples of p that fe_sub_wide / fe_sub2_wide add, fe29.h) — so that
 // x - jPx, y - jPy and s^2 - jPx - x cost one limb-wise add (two for the last) instead of two (three): 36 VALU
@@ -264,7 +275,7 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     fe_mul(acc, dx, acc);
     ws_store<0>(wr, k, xw);
     ws_store<2>(wr, k, yw);
-    if (!KG_WS_PAIRS || (k & 1)) {
+    if (!KG_WS_PAIRS || (k & (WS_GROUP - 1)) == WS_GROUP - 1) {
       pk256 qw;
       fe_settle<2, 2>(acc);
       fe_pack(qw, acc);
@@ -386,7 +397,19 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
     ws_load<2>(A.y, wr, id_at(0));
     ws_load<0>(B.x, wr, id_at(1));
     ws_load<2>(B.y, wr, id_at(1));
+#if KG_WS_QUADS
+    // QB holds the quad's stored product q_D (in slot of the next quad's first kangaroo); R, S the x of C and D, which
+    // the quad's first pair needs for q_B = dx_C * dx_D * q_D
+    pk256 R, S;
+    ws_load<0>(R, wr, id_at(2));
+    ws_load<0>(S, wr, id_at(3));
+    ws_load<4>(QB, wr, K > 4 ? id_at(4) : id_at(3));
+    fe qC, qD;  // live from the first pair of a quad to its second
+#pragma unroll
+    for (int i = 0; i < 9; ++i) qC.l[i] = qD.l[i] = 0;
+#else
     ws_load<4>(QB, wr, K > 2 ? id_at(2) : id_at(1));
+#endif
 #if !KG_WS_PAIRS
     pk256 QA;  // product of the dx still to come after A: what B's slot holds from the previous pass
     ws_load<4>(QA, wr, id_at(1));
@@ -504,6 +527,31 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       fe xA, xB, qB;
       fe_unpack(xA, A.x);
       fe_unpack(xB, B.x);
+#if KG_WS_QUADS
+      const bool first = (s & 2u) == 0;       // first pair (A, B) of its quad; the second is (C, D)
+      const u32 q0 = s & ~2u;                 // position of the quad's A
+      const bool lastq = q0 + 4 >= K;         // nothing comes after this quad's D: q_D = 1
+      fe xC, xD;
+      if (first) {
+        fe_unpack(xC, R);
+        fe_unpack(xD, S);
+        if (!lastq) fe_unpack(qD, QB);
+        A.x = R;  // C and D are the next pair: their x is already here
+        B.x = S;
+        __builtin_amdgcn_sched_barrier(0);
+        // the next quad's C, D and stored product (clamped at the end of the pass: valid slots, values unused)
+        const u32 n0 = lastq ? q0 : q0 + 4;
+        ws_load<0>(R, wr, id_at(n0 + 2));
+        ws_load<0>(S, wr, id_at(n0 + 3));
+        ws_load<4>(QB, wr, n0 + 4 < K ? id_at(n0 + 4) : id_at(n0 + 3));
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        ws_load<0>(A.x, wr, id_at(s2));
+        ws_load<0>(B.x, wr, id_at(s2 + 1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
       fe_unpack(qB, QB);
 #if !KG_WS_PAIRS
       fe qA;
@@ -512,11 +560,20 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       __builtin_amdgcn_sched_barrier(0);
       ws_load<0>(A.x, wr, id_at(s2));
       ws_load<0>(B.x, wr, id_at(s2 + 1));
+#ifdef KG_TIMING_QUADS
+      // TIMING EXPERIMENT ONLY (wrong results, never in the library): what a stored product per FOUR kangaroos would buy —
+      // every other pair neither loads nor stores a product and pays one more multiplication (profiles/r03_levers.txt)
+      // KG_TIMING_QUADS: 1 = no load, no store, one more multiplication; 2 = store skipped only; 3 = load skipped only;
+      // 4 = as 1 without the multiplication; 5 = as 1, the multiplication's result unused
+      const bool quad_skip = ((s >> 1) & 1u) != 0;
+      if (!quad_skip || KG_TIMING_QUADS == 2)
+#endif
       ws_load<4>(QB, wr, s2 + 2 < K ? id_at(s2 + 2) : id_at(s2 + 1));
 #if !KG_WS_PAIRS
       ws_load<4>(QA, wr, id_at(s2 + 1));
 #endif
       __builtin_amdgcn_sched_barrier(0);
+#endif  // KG_WS_QUADS
 
       const u32 jmpA = xA.l[0] & (NB_JUMP - 1), jmpB = xB.l[0] & (NB_JUMP - 1);
       hist_run[(u64)(idB >> 1) * threads] = (unsigned short)(asc ? (jmpA | (jmpB << 8)) : (jmpB | (jmpA << 8)));
@@ -531,7 +588,45 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
       fe_sub_wide(dxA, xA, jxA);
       fe_sub_wide(dxB, xB, jxB);
 #endif
-#if KG_WS_PAIRS
+#if KG_WS_QUADS
+      {
+        // first pair of a quad: q_C = dx_D * q_D, q_B = dx_C * q_C, q_A = dx_B * q_B (q_C and q_D stay for the second pair);
+        // either pair then:     dxi_1st = q_1st * u, u *= dx_1st, dxi_2nd = q_2nd * u, u *= dx_2nd
+        fe qF, qS;
+        if (first) {
+          const u32 *rowC = jt + (xC.l[0] & (NB_JUMP - 1)) * SJT_STRIDE, *rowD = jt + (xD.l[0] & (NB_JUMP - 1)) * SJT_STRIDE;
+          fe jxC, jxD, dxC, dxD;
+          jt_load9(jxC, rowC);
+          jt_load9(jxD, rowD);
+#if KG_JT_NEG
+          fe_add_lifted(dxC, xC, jxC);
+          fe_add_lifted(dxD, xD, jxD);
+#else
+          fe_sub_wide(dxC, xC, jxC);
+          fe_sub_wide(dxD, xD, jxD);
+#endif
+          if (!lastq) {
+            fe_mul(qC, dxD, qD);
+          } else {  // nothing comes after D: q_D = 1, q_C = dx_D — as a weak value: it is fe_mul's second operand below
+            qC = dxD;
+            fe_weak(qC);
+          }
+          fe_mul(qS, dxC, qC);
+          fe_mul(qF, dxB, qS);
+        } else {
+          qF = qC;
+          qS = qD;
+        }
+        fe_mul(dxiA, qF, u);
+        fe_mul(u, dxA, u);
+        if (first || !lastq) {
+          fe_mul(dxiB, qS, u);
+          fe_mul(u, dxB, u);
+        } else {  // D of the last quad
+          dxiB = u;
+        }
+      }
+#elif KG_WS_PAIRS
       if (!last) {
         fe qA;
         fe_mul(qA, dxB, qB);
@@ -568,7 +663,19 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
         __builtin_amdgcn_sched_barrier(0);
         ws_load<2>(B.y, wr, id_at(s2 + 1));
         __builtin_amdgcn_sched_barrier(0);
+#ifdef KG_TIMING_QUADS
+        if (quad_skip && KG_TIMING_QUADS == 1) fe_mul(acc, acc, dxiB);  // the multiplication a quad would add (any operands: timing only)
+        if (quad_skip && KG_TIMING_QUADS == 5) {  // the same multiplication with its result thrown away (the data stay what they are)
+          fe t;
+          fe_mul(t, dxiA, dxiB);
+          asm volatile("" ::"v"(t.l[0]), "v"(t.l[1]), "v"(t.l[2]), "v"(t.l[3]), "v"(t.l[4]), "v"(t.l[5]), "v"(t.l[6]), "v"(t.l[7]), "v"(t.l[8]));
+        }
+        jump(xB, yB, dxiB, jxB, rowB, idB, run, !quad_skip || KG_TIMING_QUADS == 3);
+#elif KG_WS_QUADS
+        jump(xB, yB, dxiB, jxB, rowB, idB, run, !first);  // only D stores the running product
+#else
         jump(xB, yB, dxiB, jxB, rowB, idB, run, true);
+#endif
       }
     }
   } while (++run < a.nb_run);
