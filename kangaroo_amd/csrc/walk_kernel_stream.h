@@ -76,6 +76,9 @@ constexpr u32 PACE_TAIL = 4;
 #ifndef KG_WS_QUADS
 #define KG_WS_QUADS 0
 #endif
+#ifndef KG_WS_WAVE_MAJOR
+#define KG_WS_WAVE_MAJOR 0
+#endif
 #if KG_WS_QUADS && !KG_WS_PAIRS
 #error "KG_WS_QUADS needs KG_WS_PAIRS"
 #endif
@@ -247,8 +250,15 @@ __global__ void __launch_bounds__(WALK_BLOCK, W) kg_walk_kernel_stream(StreamArg
   const u32 threads = a.threads;
   ws_ref wr;
   wr.rs = __builtin_amdgcn_make_buffer_rsrc(sa.ws, 0, (int)(WS_SLOT_WORDS * 4u * K * threads), 0x00020000);
+#if KG_WS_WAVE_MAJOR
+  // MEASUREMENT VARIANT, off in the library (profiles/r03_levers.txt): a wave's slot record (six rows of 1 KB) is
+  // contiguous and its K records follow each other, instead of every row being a run of all lanes' entries
+  wr.row_bytes = 64u * 16u;
+  wr.off = (Tl >> 6) * (K * WS_ROWS * 64u * 16u) + (Tl & 63u) * 16u;
+#else
   wr.row_bytes = threads * 16u;
   wr.off = Tl * 16u;
+#endif
 
   // jump-index history: one 16-bit entry per step, PAIR of slots (2j, 2j+1) and lane; low byte = the even slot's jump
   unsigned short *hist16 = (unsigned short *)sa.hist;
